@@ -1,0 +1,187 @@
+/* libodefilter_hip.so -- C ABI of the MI355X (gfx950) Gaussian ODE-filter hot path.
+ *
+ * Drop-in boundary for the Kalman predict / measure / calibrate / update / smooth path of
+ * ProbNumDiffEq.jl v0.1.5 (nathanaelbosch/ODEFilters.jl).  Citations are file:line in the
+ * reference tree.  A Julia host (`julia/ODEFilterHIP.jl`) binds these
+ * entry points with `ccall`; the Python host mirror (`odefilters.jl_amd/host.py`) binds the
+ * same symbols with ctypes.  Plain pointers and sizes only; no callbacks into the host.
+ *
+ * What each entry point replaces in the reference:
+ *   odef_create / odef_destroy      alg_cache(alg::GaussianODEFilter, ...)        src/caches.jl:42-114
+ *                                   (A, Q, Precond, Proj, work arrays; EK0/EK1 kwargs src/algorithms.jl:23-51)
+ *   odef_set_problem*               ODEProblem(f,u0,tspan,p) x EnsembleProblem prob_func; initialize! +
+ *                                   initial_update!                              src/perform_step.jl:2-12,
+ *                                                                                src/state_initialization.jl:2-53
+ *   odef_solve_fixed                solve(prob, alg; adaptive=false, dt) = loop of perform_step!
+ *                                                                                src/perform_step.jl:27-93
+ *                                   incl. predict!/update!                       src/filtering.jl:17-48,79-91
+ *                                   measure!                                     src/perform_step.jl:95-132
+ *                                   estimate_diffusion                           src/diffusions.jl:11-36,71-80
+ *                                   savevalues!                                  src/integrator_utils.jl:33-48
+ *   odef_solve_adaptive             same + estimate_errors                       src/perform_step.jl:78-84,148-158
+ *                                   + PI controller (exponents src/alg_utils.jl:23-24; loop is OrdinaryDiffEq's)
+ *   odef_smooth                     postamble! -> smooth_all! -> smooth!         src/integrator_utils.jl:2-30,
+ *                                                                                src/smoothing.jl:4-63
+ *   odef_get / odef_get_device      sol.t, sol.x_filt, sol.x_smooth, sol.diffusions, sol.log_likelihood,
+ *                                   sol.destats, sol.retcode                     src/solution.jl:8-24
+ *   odef_predict / odef_update /
+ *   odef_smooth_step                predict!, update!, smooth (pure functions)   src/filtering.jl:17,79,136
+ *   odef_ibm / odef_preconditioner  ibm(d,q), preconditioner(T,d,q)              src/priors.jl:7-59,
+ *                                                                                src/preconditioning.jl:1-17
+ *
+ * Error convention: every function returns 0 on success, <0 on API / HIP failure with a
+ * message in odef_last_error().  Numerical trouble is per trajectory (RETCODE field) and
+ * never aborts the batch (the reference throws / asserts: src/numerics_tricks.jl:1-6,
+ * src/smoothing.jl:25).
+ *
+ * Device data layout (all double unless noted), N = n_traj, D = d*(order+1), TRI = D(D+1)/2,
+ * trajectory index fastest so that one 64-lane wavefront (one lane per trajectory) stores
+ * 512 contiguous bytes per field element:
+ *   MEAN        [n_save][D][N]     state ordering derivative-major (src/caches.jl:63-64)
+ *   COV_TRIL    [n_save][TRI][N]   packed lower triangle, element (i,j), i>=j at i(i+1)/2+j, of
+ *                                  Sigma = L L'  (`SquarerootMatrix.mat`, src/squarerootmatrix.jl:16)
+ *   DIFFUSION   [n_save][N]        entry s = global diffusion of the step that produced save s (s>=1); [0]=0
+ *   T           [n_save] (fixed)   or [n_save][N] (adaptive)
+ *   LOGLIK      [N]                sum of per-accepted-step log-likelihoods (src/perform_step.jl:66,91)
+ *   NACCEPT, NREJECT, NF, NJAC     int32 [N]   (destats)
+ *   NSAVED      int32 [N]          number of valid saves of a trajectory (adaptive)
+ *   RETCODE     int32 [N]          odef_retcode
+ *   SMOOTH_MEAN / SMOOTH_COV_TRIL  as MEAN / COV_TRIL after odef_smooth
+ * odef_get copies a field to host memory in exactly this layout.
+ */
+#ifndef ODEFILTER_H
+#define ODEFILTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODEF_VERSION 100
+
+typedef struct odef_ctx odef_ctx;
+
+typedef enum { ODEF_EK0 = 0, ODEF_EK1 = 1 } odef_alg;
+typedef enum { ODEF_DIFFUSION_DYNAMIC = 0, ODEF_DIFFUSION_FIXED = 1 } odef_diffusion;
+typedef enum {
+  ODEF_RHS_FHN = 0,            /* u' = (c(u1 - u1^3/3 + u2), -(u1 - a - b u2)/c), p = (a,b,c) */
+  ODEF_RHS_LORENZ63 = 1,       /* p = (sigma, rho, beta) */
+  ODEF_RHS_LOTKA_VOLTERRA = 2, /* u' = (a u1 - b u1 u2, -c u2 + d u1 u2), p = (a,b,c,d) */
+  ODEF_RHS_VANDERPOL = 3,      /* u' = (u2, mu((1-u1^2)u2 - u1)), p = (mu) */
+  ODEF_RHS_LINEAR = 4,         /* u_i' = p_i u_i, d = 2 */
+  ODEF_RHS_PLEIADES = 5        /* 7-body, d = 28, no parameters */
+} odef_rhs;
+typedef enum { ODEF_SAVE_FINAL = 0, ODEF_SAVE_EVERYSTEP = 1 } odef_save_mode;
+typedef enum {
+  ODEF_RET_SUCCESS = 0,
+  ODEF_RET_MAXITERS = 1,
+  ODEF_RET_DT_LESS_THAN_MIN = 2,
+  ODEF_RET_UNSTABLE = 3,       /* NaN/Inf in the state */
+  ODEF_RET_NEGATIVE_VARIANCE = 4
+} odef_retcode;
+typedef enum {
+  ODEF_F_MEAN = 0,
+  ODEF_F_COV_TRIL = 1,
+  ODEF_F_DIFFUSION = 2,
+  ODEF_F_T = 3,
+  ODEF_F_LOGLIK = 4,
+  ODEF_F_NACCEPT = 5,
+  ODEF_F_NREJECT = 6,
+  ODEF_F_NF = 7,
+  ODEF_F_NJAC = 8,
+  ODEF_F_NSAVED = 9,
+  ODEF_F_RETCODE = 10,
+  ODEF_F_SMOOTH_MEAN = 11,
+  ODEF_F_SMOOTH_COV_TRIL = 12,
+  ODEF_F_U0 = 13,              /* [d][N] initial values as held on the device */
+  ODEF_F_COUNT_
+} odef_field;
+
+/* POD mirror of the reference's keyword structs (src/algorithms.jl:23-28,46-51) plus the
+ * ensemble shape.  Zero-initialise, set struct_size = sizeof(odef_config). */
+typedef struct {
+  int32_t struct_size;
+  int32_t alg;           /* odef_alg */
+  int32_t order;         /* q, 1..ODEF_MAX_ORDER */
+  int32_t diffusion;     /* odef_diffusion */
+  int32_t smooth;        /* keep what odef_smooth needs (forces ODEF_SAVE_EVERYSTEP) */
+  int32_t rhs_id;        /* odef_rhs */
+  int32_t d;             /* must equal the registry's dimension for rhs_id */
+  int32_t n_params;      /* must equal the registry's parameter count */
+  int32_t params_shared; /* 1: one parameter vector for all trajectories; 0: p[N][n_params] */
+  int32_t save_mode;     /* odef_save_mode */
+  int32_t device;        /* HIP device ordinal, -1 = current device */
+  int32_t want_loglik;   /* accumulate sol.log_likelihood (src/perform_step.jl:66) */
+  int64_t n_traj;        /* N */
+} odef_config;
+
+/* OrdinaryDiffEq PI step-size controller (third-party defaults; exponents from
+ * src/alg_utils.jl:23-24).  Pass NULL to odef_solve_adaptive for these defaults. */
+typedef struct {
+  double beta1, beta2, gamma, qmin, qmax, qsteady_min, qsteady_max, qoldinit, dtmin, dtmax;
+} odef_controller;
+
+#define ODEF_MAX_ORDER 5
+
+int odef_version(void);
+const char* odef_last_error(const odef_ctx* ctx); /* ctx may be NULL: last error of odef_create */
+
+int odef_create(odef_ctx** out, const odef_config* cfg);
+void odef_destroy(odef_ctx* ctx);
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the ctx's own. */
+int odef_set_stream(odef_ctx* ctx, void* hip_stream);
+
+/* Initial values.  Host layouts are trajectory-major: u0[N][d], p[N][n_params] (or
+ * p[n_params] when params_shared) -- i.e. Julia's d x N column-major matrices. */
+int odef_set_problem(odef_ctx* ctx, const double* u0, const double* p, double t0);
+/* Same from device memory already in the device layout u0[d][N], p[n_params][N]. */
+int odef_set_problem_device(odef_ctx* ctx, const double* d_u0, const double* d_p, double t0);
+/* Synthetic ensemble generated on the device (the EnsembleProblem prob_func of SURVEY 8d):
+ * u0_i[k] = base_u0[k] + scale*(2U-1) for k < n_perturbed, U = (splitmix64(seed +
+ * n_perturbed*(first_index+i) + k) >> 11) * 2^-53.  p = shared parameter vector. */
+int odef_set_problem_perturbed(odef_ctx* ctx, const double* base_u0, const double* p, double t0,
+                               double scale, uint64_t seed, int64_t first_index, int32_t n_perturbed);
+
+/* Fixed-step filter over the host time grid tgrid[0..n_t-1] (n_t-1 steps for every trajectory). */
+int odef_solve_fixed(odef_ctx* ctx, const double* tgrid, int64_t n_t);
+/* Adaptive filter from t0 to t1; at most max_steps accepted steps are stored per trajectory. */
+int odef_solve_adaptive(odef_ctx* ctx, double t1, double abstol, double reltol, double dt0,
+                        const odef_controller* ctrl, int64_t max_steps);
+/* Rauch-Tung-Striebel pass over the stored filter states. */
+int odef_smooth(odef_ctx* ctx);
+
+int64_t odef_n_save(const odef_ctx* ctx); /* leading dimension of MEAN/COV_TRIL/DIFFUSION/T */
+int odef_field_bytes(const odef_ctx* ctx, int field, size_t* bytes);
+int odef_get(odef_ctx* ctx, int field, void* host_dst, size_t bytes);
+int odef_get_device(odef_ctx* ctx, int field, void** dev_ptr, size_t* bytes);
+/* Use a caller-owned device buffer for an output field (before odef_solve_*). */
+int odef_bind_device(odef_ctx* ctx, int field, void* dev_ptr, size_t bytes);
+int odef_synchronize(odef_ctx* ctx);
+
+/* Device time of the last filter (which=0) / smoother (which=1) launch, measured with
+ * hipEvents on the launch stream; n_launches = kernels launched by that call. */
+int odef_kernel_time_ms(odef_ctx* ctx, int which, float* ms, int* n_launches);
+
+/* Constants (host side, for tests and host mirrors). A, Q_L: D x D row-major. */
+int odef_ibm(int d, int q, double* A, double* Q_L);
+int odef_preconditioner(int d, int q, double h, double* P_diag);
+
+/* Step-level entry points on batched Gaussians held in HOST memory (copied to the device,
+ * computed by HIP kernels, copied back).  n instances; mu[n][D]; L[n][D][D] row-major
+ * square-root factors (Sigma = L L'); A, Q_L: D x D row-major shared by the batch.
+ * D <= ODEF_MAX_STEP_DIM. */
+#define ODEF_MAX_STEP_DIM 32
+int odef_predict(int D, int64_t n, const double* mu, const double* L, const double* A, const double* Q_L,
+                 double* mu_out, double* cov_out /* [n][D][D] full symmetric */);
+/* measurement Z = N(z, S) with S = H Sigma_pred H' (R = 0, asserted by the reference at src/filtering.jl:81) */
+int odef_update(int D, int o, int64_t n, const double* mu_pred, const double* L_pred, const double* H /* [n][o][D] */,
+                const double* z /* [n][o] */, double* mu_out, double* cov_out /* [n][D][D] */);
+int odef_smooth_step(int D, int64_t n, const double* mu, const double* L, const double* mu_s, const double* L_s,
+                     const double* A, const double* Q_L, double* mu_out, double* cov_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODEFILTER_H */

@@ -1,0 +1,625 @@
+// C-ABI layer of libodefilter_hip.so (see include/odefilter.h for the contract and the
+// reference interfaces each entry point replaces).  Owns device buffers, builds the prior
+// tables (src/priors.jl:7-59) and the per-step preconditioner seeds
+// (src/preconditioning.jl:9) on the host, launches the gfx950 kernels, times them with
+// hipEvents on the launch stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/odefilter.h"
+#include "launch.h"
+
+using namespace odef;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Buf {
+  void* ptr = nullptr;
+  size_t bytes = 0;     // capacity
+  size_t valid = 0;     // bytes holding results
+  bool owned = false;
+  bool bound = false;
+};
+
+struct RhsInfo { int d, np; };
+const RhsInfo kRhs[] = {{2, 3}, {3, 3}, {2, 4}, {2, 1}, {2, 2}, {28, 0}};
+
+}  // namespace
+
+struct odef_ctx {
+  odef_config cfg{};
+  int d = 0, q = 0, D = 0, TRI = 0, np = 0;
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  PriorConsts pc{};
+  double* d_u0 = nullptr;
+  double* d_p = nullptr;
+  bool have_problem = false;
+  double t0 = 0.0;
+  // time grid of the last fixed solve
+  std::vector<double> tgrid;
+  double* d_hs = nullptr;
+  double* d_pvals = nullptr;
+  double* d_tgrid = nullptr;
+  size_t grid_cap = 0;
+  long n_save = 0;
+  bool adaptive = false;
+  bool solved = false;
+  Buf f[ODEF_F_COUNT_];
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  float ms[2] = {0.f, 0.f};
+  int nl[2] = {0, 0};
+  std::string err;
+};
+
+namespace {
+
+int fail(odef_ctx* c, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  else g_create_error = buf;
+  return -1;
+}
+
+#define HIPCHK(c, call)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) return fail((c), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// ibm(d,q) reduced to its (q+1)x(q+1) scalar blocks (src/priors.jl:15-56).
+void build_prior(int q, PriorConsts& pc) {
+  std::memset(&pc, 0, sizeof pc);
+  const int nb = q + 1;
+  for (int J = 0; J < nb; ++J) {
+    pc.At[J][J] = 1.0;
+  }
+  {
+    double val = 1.0;
+    for (int i = 1; i <= q; ++i) {  // A[j, j+d*i] = 1/i!  by the reference's running division
+      val = val / i;
+      for (int J = 0; J + i < nb; ++J) pc.At[J][J + i] = val;
+    }
+  }
+  auto fact = [](int n) { double f = 1.0; for (int k = 2; k <= n; ++k) f *= k; return f; };
+  for (int c = 0; c < nb; ++c)
+    for (int r = c; r < nb; ++r) {
+      const double idx = 2 * q + 1 - r - c;
+      const double v = 1.0 / (idx * fact(q - r) * fact(q - c));
+      pc.Qt[r][c] = v;
+      pc.Qt[c][r] = v;
+    }
+  // QLt = cholesky(Qt).L   (chol(Qt (x) I) == chol(Qt) (x) I)
+  for (int j = 0; j < nb; ++j) {
+    double s = pc.Qt[j][j];
+    for (int k = 0; k < j; ++k) s -= pc.QLt[j][k] * pc.QLt[j][k];
+    pc.QLt[j][j] = std::sqrt(s);
+    for (int i = j + 1; i < nb; ++i) {
+      double t = pc.Qt[i][j];
+      for (int k = 0; k < j; ++k) t -= pc.QLt[i][k] * pc.QLt[j][k];
+      pc.QLt[i][j] = t / pc.QLt[j][j];
+    }
+  }
+}
+
+size_t field_elem(int field) {
+  switch (field) {
+    case ODEF_F_NACCEPT: case ODEF_F_NREJECT: case ODEF_F_NF: case ODEF_F_NJAC: case ODEF_F_NSAVED: case ODEF_F_RETCODE:
+      return sizeof(int32_t);
+    default: return sizeof(double);
+  }
+}
+
+// number of elements of a field for the current solve shape
+size_t field_count(const odef_ctx* c, int field, long n_save) {
+  const size_t N = (size_t)c->cfg.n_traj;
+  switch (field) {
+    case ODEF_F_MEAN: case ODEF_F_SMOOTH_MEAN: return (size_t)n_save * c->D * N;
+    case ODEF_F_COV_TRIL: case ODEF_F_SMOOTH_COV_TRIL: return (size_t)n_save * c->TRI * N;
+    case ODEF_F_DIFFUSION: return (size_t)n_save * N;
+    case ODEF_F_T: return c->adaptive ? (size_t)n_save * N : (size_t)n_save;
+    case ODEF_F_U0: return (size_t)c->d * N;
+    default: return N;
+  }
+}
+
+int ensure(odef_ctx* c, int field, size_t bytes) {
+  Buf& b = c->f[field];
+  if (b.bound) {
+    if (b.bytes < bytes) return fail(c, "bound buffer for field %d too small: %zu < %zu bytes", field, b.bytes, bytes);
+    b.valid = bytes;
+    return 0;
+  }
+  if (b.bytes < bytes) {
+    if (b.ptr) HIPCHK(c, hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.bytes = 0;
+    HIPCHK(c, hipMalloc(&b.ptr, bytes));
+    b.bytes = bytes;
+    b.owned = true;
+  }
+  b.valid = bytes;
+  return 0;
+}
+
+int set_device(odef_ctx* c) {
+  HIPCHK(c, hipSetDevice(c->device));
+  return 0;
+}
+
+__global__ void transpose_in_kernel(const double* __restrict__ src /*[N][k]*/, double* __restrict__ dst /*[k][N]*/,
+                                    long N, int k) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  for (int a = 0; a < k; ++a) dst[(size_t)a * N + i] = src[(size_t)i * k + a];
+}
+
+__device__ inline unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  unsigned long long z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+struct PerturbArgs { double base[32]; };
+
+__global__ void perturbed_u0_kernel(PerturbArgs a, double* __restrict__ dst /*[d][N]*/, long N, int d, int n_pert,
+                                    double scale, unsigned long long seed, long first) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  for (int k = 0; k < d; ++k) {
+    double v = a.base[k];
+    if (k < n_pert) {
+      const unsigned long long r = splitmix64(seed + (unsigned long long)n_pert * (unsigned long long)(first + i) + k);
+      const double U = (double)(r >> 11) * 0x1.0p-53;
+      v = a.base[k] + scale * (2.0 * U - 1.0);
+    }
+    dst[(size_t)k * N + i] = v;
+  }
+}
+
+__global__ void scale_cov_kernel(double* __restrict__ cov, const double* __restrict__ diff_last, double* __restrict__ diff,
+                                 double* __restrict__ loglik, long N, long n_save, int TRI) {
+  // postamble! for static diffusion (src/integrator_utils.jl:4-18): Sigma *= final_diff, diffusions .= final_diff,
+  // sol.log_likelihood = NaN
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double s = diff_last[i];
+  for (long n = 0; n < n_save; ++n) {
+    for (int k = 0; k < TRI; ++k) cov[((size_t)n * TRI + k) * N + i] *= s;
+    if (n >= 1) diff[(size_t)n * N + i] = s;
+  }
+  loglik[i] = __builtin_nan("");
+}
+
+}  // namespace
+
+extern "C" {
+
+int odef_version(void) { return ODEF_VERSION; }
+
+const char* odef_last_error(const odef_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int odef_create(odef_ctx** out, const odef_config* cfg) {
+  if (!out || !cfg) return fail(nullptr, "odef_create: null argument");
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(odef_config))
+    return fail(nullptr, "odef_create: struct_size %d != %zu", cfg->struct_size, sizeof(odef_config));
+  if (cfg->rhs_id < 0 || cfg->rhs_id > ODEF_RHS_PLEIADES) return fail(nullptr, "odef_create: unknown rhs_id %d", cfg->rhs_id);
+  const RhsInfo ri = kRhs[cfg->rhs_id];
+  if (cfg->d != ri.d) return fail(nullptr, "odef_create: rhs %d has dimension %d, got d=%d", cfg->rhs_id, ri.d, cfg->d);
+  if (cfg->n_params != ri.np) return fail(nullptr, "odef_create: rhs %d has %d parameters, got %d", cfg->rhs_id, ri.np, cfg->n_params);
+  if (cfg->order < 1 || cfg->order > ODEF_MAX_ORDER) return fail(nullptr, "odef_create: order %d outside 1..%d", cfg->order, ODEF_MAX_ORDER);
+  if (cfg->alg != ODEF_EK0 && cfg->alg != ODEF_EK1) return fail(nullptr, "odef_create: unknown alg %d", cfg->alg);
+  if (cfg->diffusion != ODEF_DIFFUSION_DYNAMIC && cfg->diffusion != ODEF_DIFFUSION_FIXED)
+    return fail(nullptr, "odef_create: unknown diffusion model %d", cfg->diffusion);
+  if (cfg->n_traj <= 0) return fail(nullptr, "odef_create: n_traj must be positive");
+  if (cfg->rhs_id == ODEF_RHS_PLEIADES) return fail(nullptr, "odef_create: rhs PLEIADES (D=168 workgroup kernel) is not built yet");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, "odef_create: no HIP device available (libodefilter_hip has no CPU path)");
+  odef_ctx* c = new odef_ctx();
+  c->cfg = *cfg;
+  if (c->cfg.smooth) c->cfg.save_mode = ODEF_SAVE_EVERYSTEP;
+  c->d = cfg->d;
+  c->q = cfg->order;
+  c->D = c->d * (c->q + 1);
+  c->TRI = c->D * (c->D + 1) / 2;
+  c->np = cfg->n_params;
+  if (cfg->device >= 0) c->device = cfg->device;
+  else if (hipGetDevice(&c->device) != hipSuccess) c->device = 0;
+  if (c->device >= ndev) { delete c; return fail(nullptr, "odef_create: device %d not present (%d devices)", cfg->device, ndev); }
+  build_prior(c->q, c->pc);
+  hipError_t e = hipSetDevice(c->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev[k]);
+  const size_t N = (size_t)cfg->n_traj;
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_u0, sizeof(double) * c->d * N);
+  if (e == hipSuccess && c->np > 0) e = hipMalloc((void**)&c->d_p, sizeof(double) * c->np * (cfg->params_shared ? 1 : N));
+  if (e != hipSuccess) {
+    fail(nullptr, "odef_create: HIP setup failed: %s", hipGetErrorString(e));
+    odef_destroy(c);
+    return -1;
+  }
+  c->stream = c->own_stream;
+  c->f[ODEF_F_U0].ptr = c->d_u0;
+  c->f[ODEF_F_U0].bytes = c->f[ODEF_F_U0].valid = sizeof(double) * c->d * N;
+  *out = c;
+  return 0;
+}
+
+void odef_destroy(odef_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  for (int k = 0; k < ODEF_F_COUNT_; ++k)
+    if (k != ODEF_F_U0 && c->f[k].owned && c->f[k].ptr) (void)hipFree(c->f[k].ptr);
+  if (c->d_u0) (void)hipFree(c->d_u0);
+  if (c->d_p) (void)hipFree(c->d_p);
+  if (c->d_hs) (void)hipFree(c->d_hs);
+  if (c->d_pvals) (void)hipFree(c->d_pvals);
+  if (c->d_tgrid) (void)hipFree(c->d_tgrid);
+  for (int k = 0; k < 4; ++k)
+    if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int odef_set_stream(odef_ctx* c, void* hip_stream) {
+  if (!c) return -1;
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return 0;
+}
+
+int odef_set_problem(odef_ctx* c, const double* u0, const double* p, double t0) {
+  if (!c || !u0) return fail(c, "odef_set_problem: null argument");
+  if (c->np > 0 && !p) return fail(c, "odef_set_problem: parameters required");
+  if (set_device(c)) return -1;
+  const long N = c->cfg.n_traj;
+  double* tmp = nullptr;
+  const size_t ub = sizeof(double) * c->d * N;
+  const size_t pb = (c->np > 0 && !c->cfg.params_shared) ? sizeof(double) * c->np * N : 0;
+  HIPCHK(c, hipMalloc((void**)&tmp, ub > pb ? ub : pb));
+  HIPCHK(c, hipMemcpyAsync(tmp, u0, ub, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(transpose_in_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, tmp, c->d_u0, N, c->d);
+  if (c->np > 0) {
+    if (c->cfg.params_shared) {
+      HIPCHK(c, hipMemcpyAsync(c->d_p, p, sizeof(double) * c->np, hipMemcpyHostToDevice, c->stream));
+    } else {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipMemcpyAsync(tmp, p, pb, hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(transpose_in_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, tmp, c->d_p, N, c->np);
+    }
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipFree(tmp));
+  c->t0 = t0;
+  c->have_problem = true;
+  return 0;
+}
+
+int odef_set_problem_device(odef_ctx* c, const double* d_u0, const double* d_p, double t0) {
+  if (!c || !d_u0) return fail(c, "odef_set_problem_device: null argument");
+  if (c->np > 0 && !d_p) return fail(c, "odef_set_problem_device: parameters required");
+  if (set_device(c)) return -1;
+  const size_t N = (size_t)c->cfg.n_traj;
+  HIPCHK(c, hipMemcpyAsync(c->d_u0, d_u0, sizeof(double) * c->d * N, hipMemcpyDeviceToDevice, c->stream));
+  if (c->np > 0)
+    HIPCHK(c, hipMemcpyAsync(c->d_p, d_p, sizeof(double) * c->np * (c->cfg.params_shared ? 1 : N), hipMemcpyDeviceToDevice, c->stream));
+  c->t0 = t0;
+  c->have_problem = true;
+  return 0;
+}
+
+int odef_set_problem_perturbed(odef_ctx* c, const double* base_u0, const double* p, double t0, double scale,
+                               uint64_t seed, int64_t first_index, int32_t n_perturbed) {
+  if (!c || !base_u0) return fail(c, "odef_set_problem_perturbed: null argument");
+  if (c->np > 0 && !p) return fail(c, "odef_set_problem_perturbed: parameters required");
+  if (!c->cfg.params_shared && c->np > 0) return fail(c, "odef_set_problem_perturbed: needs params_shared = 1");
+  if (n_perturbed < 0 || n_perturbed > c->d) return fail(c, "odef_set_problem_perturbed: n_perturbed %d outside 0..%d", n_perturbed, c->d);
+  if (set_device(c)) return -1;
+  PerturbArgs a;
+  for (int k = 0; k < c->d; ++k) a.base[k] = base_u0[k];
+  const long N = c->cfg.n_traj;
+  hipLaunchKernelGGL(perturbed_u0_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, a, c->d_u0, N, c->d,
+                     (int)n_perturbed, scale, (unsigned long long)seed, (long)first_index);
+  HIPCHK(c, hipGetLastError());
+  if (c->np > 0) HIPCHK(c, hipMemcpyAsync(c->d_p, p, sizeof(double) * c->np, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->t0 = t0;
+  c->have_problem = true;
+  return 0;
+}
+
+static int alloc_outputs(odef_ctx* c, long n_save) {
+  static const int per_save[] = {ODEF_F_MEAN, ODEF_F_COV_TRIL, ODEF_F_DIFFUSION};
+  for (int f : per_save)
+    if (ensure(c, f, field_count(c, f, n_save) * sizeof(double))) return -1;
+  if (c->adaptive && ensure(c, ODEF_F_T, field_count(c, ODEF_F_T, n_save) * sizeof(double))) return -1;
+  static const int per_traj[] = {ODEF_F_LOGLIK, ODEF_F_NACCEPT, ODEF_F_NREJECT, ODEF_F_NF, ODEF_F_NJAC, ODEF_F_NSAVED, ODEF_F_RETCODE};
+  for (int f : per_traj)
+    if (ensure(c, f, (size_t)c->cfg.n_traj * field_elem(f))) return -1;
+  return 0;
+}
+
+static void fill_params(odef_ctx* c, FilterParams& P) {
+  std::memset(&P, 0, sizeof P);
+  P.pc = c->pc;
+  P.u0 = c->d_u0;
+  P.p = c->d_p;
+  P.p_shared = c->cfg.params_shared;
+  P.N = c->cfg.n_traj;
+  P.everystep = c->cfg.save_mode == ODEF_SAVE_EVERYSTEP;
+  P.fixed_diffusion = c->cfg.diffusion == ODEF_DIFFUSION_FIXED;
+  P.want_loglik = c->cfg.want_loglik;
+  P.mean = (double*)c->f[ODEF_F_MEAN].ptr;
+  P.cov = (double*)c->f[ODEF_F_COV_TRIL].ptr;
+  P.diff = (double*)c->f[ODEF_F_DIFFUSION].ptr;
+  P.tsave = (double*)c->f[ODEF_F_T].ptr;
+  P.loglik = (double*)c->f[ODEF_F_LOGLIK].ptr;
+  P.naccept = (int*)c->f[ODEF_F_NACCEPT].ptr;
+  P.nreject = (int*)c->f[ODEF_F_NREJECT].ptr;
+  P.nf = (int*)c->f[ODEF_F_NF].ptr;
+  P.njac = (int*)c->f[ODEF_F_NJAC].ptr;
+  P.nsaved = (int*)c->f[ODEF_F_NSAVED].ptr;
+  P.retcode = (int*)c->f[ODEF_F_RETCODE].ptr;
+}
+
+static int finish_filter(odef_ctx* c, int nlaunch) {
+  // static diffusion: rescale all covariances by the final global diffusion (src/integrator_utils.jl:4-18)
+  if (c->cfg.diffusion == ODEF_DIFFUSION_FIXED && !c->adaptive) {
+    const long N = c->cfg.n_traj;
+    double* diff = (double*)c->f[ODEF_F_DIFFUSION].ptr;
+    hipLaunchKernelGGL(scale_cov_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, c->stream,
+                       (double*)c->f[ODEF_F_COV_TRIL].ptr, diff + (size_t)(c->n_save - 1) * N, diff,
+                       (double*)c->f[ODEF_F_LOGLIK].ptr, N, c->n_save, c->TRI);
+    ++nlaunch;
+  }
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventSynchronize(c->ev[1]));
+  HIPCHK(c, hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]));
+  c->nl[0] = nlaunch;
+  c->solved = true;
+  return 0;
+}
+
+int odef_solve_fixed(odef_ctx* c, const double* tgrid, int64_t n_t) {
+  if (!c || !tgrid) return fail(c, "odef_solve_fixed: null argument");
+  if (!c->have_problem) return fail(c, "odef_solve_fixed: call odef_set_problem first");
+  if (n_t < 2) return fail(c, "odef_solve_fixed: need at least two grid points (adaptive=false requires a dt)");
+  if (tgrid[0] != c->t0) return fail(c, "odef_solve_fixed: tgrid[0] = %g differs from t0 = %g", tgrid[0], c->t0);
+  for (int64_t n = 0; n + 1 < n_t; ++n)
+    if (!(tgrid[n + 1] > tgrid[n])) return fail(c, "odef_solve_fixed: tgrid must be strictly increasing (index %lld)", (long long)n);
+  if (set_device(c)) return -1;
+  const long nsteps = (long)n_t - 1;
+  c->adaptive = false;
+  c->n_save = (c->cfg.save_mode == ODEF_SAVE_EVERYSTEP) ? nsteps + 1 : 1;
+  c->tgrid.assign(tgrid, tgrid + n_t);
+  std::vector<double> hs(nsteps), pv(nsteps);
+  for (long n = 0; n < nsteps; ++n) {
+    hs[n] = tgrid[n + 1] - tgrid[n];
+    pv[n] = std::pow(hs[n], -c->q - 0.5);  // src/preconditioning.jl:9
+  }
+  if (c->grid_cap < (size_t)n_t) {
+    if (c->d_hs) { HIPCHK(c, hipFree(c->d_hs)); HIPCHK(c, hipFree(c->d_pvals)); HIPCHK(c, hipFree(c->d_tgrid)); }
+    c->d_hs = c->d_pvals = c->d_tgrid = nullptr;
+    HIPCHK(c, hipMalloc((void**)&c->d_hs, sizeof(double) * n_t));
+    HIPCHK(c, hipMalloc((void**)&c->d_pvals, sizeof(double) * n_t));
+    HIPCHK(c, hipMalloc((void**)&c->d_tgrid, sizeof(double) * n_t));
+    c->grid_cap = (size_t)n_t;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_hs, hs.data(), sizeof(double) * nsteps, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_pvals, pv.data(), sizeof(double) * nsteps, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_tgrid, tgrid, sizeof(double) * n_t, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // hs/pv are stack-owned host vectors
+  if (alloc_outputs(c, c->n_save)) return -1;
+  FilterParams P;
+  fill_params(c, P);
+  P.hs = c->d_hs;
+  P.pvals = c->d_pvals;
+  P.tgrid = c->d_tgrid;
+  P.nsteps = nsteps;
+  P.t0 = c->t0;
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  const int rc = launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 0, P, c->stream);
+  if (rc) return fail(c, "odef_solve_fixed: no kernel for rhs %d order %d", c->cfg.rhs_id, c->q);
+  return finish_filter(c, 1);
+}
+
+int odef_solve_adaptive(odef_ctx* c, double t1, double abstol, double reltol, double dt0, const odef_controller* ctrl,
+                        int64_t max_steps) {
+  if (!c) return -1;
+  if (!c->have_problem) return fail(c, "odef_solve_adaptive: call odef_set_problem first");
+  if (!(t1 > c->t0)) return fail(c, "odef_solve_adaptive: t1 must exceed t0");
+  if (!(dt0 > 0.0)) return fail(c, "odef_solve_adaptive: dt0 must be positive");
+  if (max_steps < 1) return fail(c, "odef_solve_adaptive: max_steps must be >= 1");
+  if (c->cfg.save_mode != ODEF_SAVE_EVERYSTEP) return fail(c, "odef_solve_adaptive: needs ODEF_SAVE_EVERYSTEP");
+  if (set_device(c)) return -1;
+  c->adaptive = true;
+  c->n_save = (long)max_steps + 1;
+  c->tgrid.clear();
+  if (alloc_outputs(c, c->n_save)) return -1;
+  FilterParams P;
+  fill_params(c, P);
+  P.t0 = c->t0;
+  P.t1 = t1;
+  P.abstol = abstol;
+  P.reltol = reltol;
+  P.dt0 = dt0;
+  P.max_save = c->n_save;
+  if (ctrl) {
+    std::memcpy(&P.ctrl, ctrl, sizeof(Controller));
+  } else {  // OrdinaryDiffEq defaults with src/alg_utils.jl:23-24 exponents
+    P.ctrl = Controller{7.0 / (10.0 * (c->q + 1)), 2.0 / (5.0 * (c->q + 1)), 0.9, 0.2, 10.0, 1.0, 1.0, 1e-4, 0.0, 1e300};
+  }
+  HIPCHK(c, hipMemsetAsync(c->f[ODEF_F_T].ptr, 0, c->f[ODEF_F_T].valid, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  const int rc = launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 1, P, c->stream);
+  if (rc) return fail(c, "odef_solve_adaptive: no kernel for rhs %d order %d", c->cfg.rhs_id, c->q);
+  return finish_filter(c, 1);
+}
+
+int odef_smooth(odef_ctx* c) {
+  if (!c) return -1;
+  if (!c->solved) return fail(c, "odef_smooth: nothing to smooth, call odef_solve_* first");
+  if (c->cfg.save_mode != ODEF_SAVE_EVERYSTEP) return fail(c, "odef_smooth: needs ODEF_SAVE_EVERYSTEP (cfg.smooth = 1)");
+  if (set_device(c)) return -1;
+  if (ensure(c, ODEF_F_SMOOTH_MEAN, field_count(c, ODEF_F_SMOOTH_MEAN, c->n_save) * sizeof(double))) return -1;
+  if (ensure(c, ODEF_F_SMOOTH_COV_TRIL, field_count(c, ODEF_F_SMOOTH_COV_TRIL, c->n_save) * sizeof(double))) return -1;
+  SmoothParams S;
+  std::memset(&S, 0, sizeof S);
+  S.pc = c->pc;
+  S.N = c->cfg.n_traj;
+  S.n_save = c->n_save;
+  S.adaptive = c->adaptive;
+  S.hs = c->d_hs;
+  S.pvals = c->d_pvals;
+  S.tsave = (const double*)c->f[ODEF_F_T].ptr;
+  S.nsaved = (const int*)c->f[ODEF_F_NSAVED].ptr;
+  S.mean = (const double*)c->f[ODEF_F_MEAN].ptr;
+  S.cov = (const double*)c->f[ODEF_F_COV_TRIL].ptr;
+  S.diff = (const double*)c->f[ODEF_F_DIFFUSION].ptr;
+  S.smean = (double*)c->f[ODEF_F_SMOOTH_MEAN].ptr;
+  S.scov = (double*)c->f[ODEF_F_SMOOTH_COV_TRIL].ptr;
+  S.retcode = (int*)c->f[ODEF_F_RETCODE].ptr;
+  if (c->adaptive) {  // unused save slots stay defined
+    HIPCHK(c, hipMemsetAsync(S.smean, 0, c->f[ODEF_F_SMOOTH_MEAN].valid, c->stream));
+    HIPCHK(c, hipMemsetAsync(S.scov, 0, c->f[ODEF_F_SMOOTH_COV_TRIL].valid, c->stream));
+  }
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  const int rc = launch_smooth(c->d, c->q, S, c->stream);
+  if (rc) return fail(c, "odef_smooth: no kernel for d %d order %d", c->d, c->q);
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventSynchronize(c->ev[3]));
+  HIPCHK(c, hipEventElapsedTime(&c->ms[1], c->ev[2], c->ev[3]));
+  c->nl[1] = 1;
+  return 0;
+}
+
+int64_t odef_n_save(const odef_ctx* c) { return c ? c->n_save : -1; }
+
+int odef_field_bytes(const odef_ctx* c, int field, size_t* bytes) {
+  if (!c || !bytes || field < 0 || field >= ODEF_F_COUNT_) return -1;
+  if (field == ODEF_F_T && !c->adaptive) { *bytes = c->tgrid.size() ? (size_t)c->n_save * sizeof(double) : 0; return 0; }
+  *bytes = c->f[field].valid;
+  return 0;
+}
+
+int odef_get(odef_ctx* c, int field, void* host_dst, size_t bytes) {
+  if (!c || !host_dst) return fail(c, "odef_get: null argument");
+  if (field < 0 || field >= ODEF_F_COUNT_) return fail(c, "odef_get: unknown field %d", field);
+  if (set_device(c)) return -1;
+  if (field == ODEF_F_T && !c->adaptive) {
+    if (c->tgrid.empty()) return fail(c, "odef_get: no solve yet");
+    const size_t need = (size_t)c->n_save * sizeof(double);
+    if (bytes != need) return fail(c, "odef_get: field T holds %zu bytes, caller asked for %zu", need, bytes);
+    if (c->n_save == 1) ((double*)host_dst)[0] = c->tgrid.back();
+    else std::memcpy(host_dst, c->tgrid.data(), need);
+    return 0;
+  }
+  const Buf& b = c->f[field];
+  if (!b.ptr || !b.valid) return fail(c, "odef_get: field %d holds no data yet", field);
+  if (bytes != b.valid) return fail(c, "odef_get: field %d holds %zu bytes, caller asked for %zu", field, b.valid, bytes);
+  HIPCHK(c, hipMemcpyAsync(host_dst, b.ptr, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int odef_get_device(odef_ctx* c, int field, void** dev_ptr, size_t* bytes) {
+  if (!c || !dev_ptr || !bytes) return fail(c, "odef_get_device: null argument");
+  if (field < 0 || field >= ODEF_F_COUNT_) return fail(c, "odef_get_device: unknown field %d", field);
+  const Buf& b = c->f[field];
+  if (!b.ptr || !b.valid) return fail(c, "odef_get_device: field %d holds no data yet", field);
+  *dev_ptr = b.ptr;
+  *bytes = b.valid;
+  return 0;
+}
+
+int odef_bind_device(odef_ctx* c, int field, void* dev_ptr, size_t bytes) {
+  if (!c) return -1;
+  if (field < 0 || field >= ODEF_F_COUNT_ || field == ODEF_F_U0) return fail(c, "odef_bind_device: field %d cannot be bound", field);
+  if (set_device(c)) return -1;
+  Buf& b = c->f[field];
+  if (b.owned && b.ptr) HIPCHK(c, hipFree(b.ptr));
+  b = Buf{};
+  if (dev_ptr) {
+    b.ptr = dev_ptr;
+    b.bytes = bytes;
+    b.bound = true;
+  }
+  return 0;
+}
+
+int odef_synchronize(odef_ctx* c) {
+  if (!c) return -1;
+  if (set_device(c)) return -1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int odef_kernel_time_ms(odef_ctx* c, int which, float* ms, int* n_launches) {
+  if (!c || which < 0 || which > 1 || !ms) return -1;
+  *ms = c->ms[which];
+  if (n_launches) *n_launches = c->nl[which];
+  return 0;
+}
+
+int odef_ibm(int d, int q, double* A, double* Q_L) {
+  if (d < 1 || q < 1 || q > ODEF_MAX_ORDER || !A || !Q_L) return -1;
+  PriorConsts pc;
+  build_prior(q, pc);
+  const int D = d * (q + 1);
+  for (int i = 0; i < D; ++i)
+    for (int j = 0; j < D; ++j) {
+      const bool same = (i % d) == (j % d);
+      A[i * D + j] = same ? pc.At[i / d][j / d] : 0.0;
+      Q_L[i * D + j] = same ? pc.QLt[i / d][j / d] : 0.0;
+    }
+  return 0;
+}
+
+int odef_preconditioner(int d, int q, double h, double* P_diag) {
+  if (d < 1 || q < 0 || !P_diag || !(h > 0.0)) return -1;
+  double val = std::pow(h, -q - 0.5);  // src/preconditioning.jl:9
+  for (int j = 0; j <= q; ++j) {
+    for (int i = 0; i < d; ++i) P_diag[j * d + i] = val;
+    val *= h;
+  }
+  return 0;
+}
+
+}  // extern "C"
+
+namespace odef {
+int launch_filter(int rhs, int q, int ek1, int adaptive, const FilterParams& P, hipStream_t s) {
+  switch (rhs) {
+    case ODEF_RHS_FHN: return launch_filter_fhn(q, ek1, adaptive, P, s);
+    case ODEF_RHS_LORENZ63: return launch_filter_lorenz63(q, ek1, adaptive, P, s);
+    case ODEF_RHS_LOTKA_VOLTERRA: return launch_filter_lotka_volterra(q, ek1, adaptive, P, s);
+    case ODEF_RHS_VANDERPOL: return launch_filter_vanderpol(q, ek1, adaptive, P, s);
+    case ODEF_RHS_LINEAR: return launch_filter_linear(q, ek1, adaptive, P, s);
+    default: return -2;
+  }
+}
+int launch_smooth(int d, int q, const SmoothParams& P, hipStream_t s) {
+  if (d == 2) return launch_smooth_d2(q, P, s);
+  if (d == 3) return launch_smooth_d3(q, P, s);
+  return -2;
+}
+}  // namespace odef

@@ -1,0 +1,50 @@
+// Kernel templates: one lane per trajectory, one 64-lane wavefront per workgroup.
+// (256 CUs x 4 SIMDs = 1024 wave slots at one wave per SIMD: 65 536 trajectories fill the
+// chip exactly once; block size 64 lets the dispatcher spread waves over all SIMDs.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dispatch.h"
+#include "launch.h"
+
+namespace odef {
+
+constexpr int kWave = 64;
+
+template <class RHS, int q, bool EK1>
+__global__ __launch_bounds__(kWave) void ek_filter_fixed_kernel(const FilterParams P) {
+  const long i = (long)blockIdx.x * kWave + threadIdx.x;
+  if (i < P.N) filter_fixed_lane<RHS, q, EK1>(P, i);
+}
+template <class RHS, int q, bool EK1>
+__global__ __launch_bounds__(kWave) void ek_filter_adaptive_kernel(const FilterParams P) {
+  const long i = (long)blockIdx.x * kWave + threadIdx.x;
+  if (i < P.N) filter_adaptive_lane<RHS, q, EK1>(P, i);
+}
+template <int d, int q>
+__global__ __launch_bounds__(kWave) void rts_smooth_kernel(const SmoothParams P) {
+  const long i = (long)blockIdx.x * kWave + threadIdx.x;
+  if (i < P.N) smooth_lane<d, q>(P, i);
+}
+
+struct LaunchFilter {
+  const FilterParams& P;
+  int adaptive;
+  hipStream_t s;
+  template <class RHS, int q, bool EK1>
+  void operator()() {
+    const unsigned grid = (unsigned)((P.N + kWave - 1) / kWave);
+    if (adaptive) hipLaunchKernelGGL((ek_filter_adaptive_kernel<RHS, q, EK1>), dim3(grid), dim3(kWave), 0, s, P);
+    else hipLaunchKernelGGL((ek_filter_fixed_kernel<RHS, q, EK1>), dim3(grid), dim3(kWave), 0, s, P);
+  }
+};
+struct LaunchSmooth {
+  const SmoothParams& P;
+  hipStream_t s;
+  template <int d, int q>
+  void operator()() {
+    const unsigned grid = (unsigned)((P.N + kWave - 1) / kWave);
+    hipLaunchKernelGGL((rts_smooth_kernel<d, q>), dim3(grid), dim3(kWave), 0, s, P);
+  }
+};
+
+}  // namespace odef

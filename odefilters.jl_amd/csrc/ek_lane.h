@@ -1,0 +1,422 @@
+// Per-trajectory drivers: fixed-step filter, adaptive filter, RTS smoother.
+// One call = the whole time loop of one trajectory (one GPU lane).  The loop that the
+// reference leaves to OrdinaryDiffEq.solve! (loopheader! -> perform_step! -> loopfooter! ->
+// savevalues!) runs on the device.
+#pragma once
+#include "ek_math.h"
+#include "rhs.h"
+
+namespace odef {
+
+struct Controller {  // mirrors odef_controller
+  double beta1, beta2, gamma, qmin, qmax, qsteady_min, qsteady_max, qoldinit, dtmin, dtmax;
+};
+
+struct FilterParams {
+  PriorConsts pc;
+  // problem
+  const double* u0;  // [d][N]
+  const double* p;   // [np][N] or [np]
+  int p_shared;
+  long N;
+  // fixed grid (device arrays of length nsteps): h_n and h_n^(-q-1/2)
+  const double* hs;
+  const double* pvals;
+  const double* tgrid;  // [nsteps+1]
+  long nsteps;
+  // adaptive
+  double t0, t1, abstol, reltol, dt0;
+  Controller ctrl;
+  long max_save;  // capacity of the save axis (adaptive)
+  // options
+  int everystep, fixed_diffusion, want_loglik;
+  // outputs
+  double* mean;    // [n_save][D][N]
+  double* cov;     // [n_save][TRI][N]
+  double* diff;    // [n_save][N]
+  double* tsave;   // [n_save][N] (adaptive only)
+  double* loglik;  // [N]
+  int* naccept;
+  int* nreject;
+  int* nf;
+  int* njac;
+  int* nsaved;
+  int* retcode;
+};
+
+template <int D, int TRI>
+__device__ inline void store_state(const FilterParams& P, long slot, long i, const double (&m)[D],
+                                   const double (&C)[TRI], double diffusion) {
+  double* __restrict__ pm = P.mean + (size_t)slot * D * P.N + i;
+#pragma unroll
+  for (int k = 0; k < D; ++k) pm[(size_t)k * P.N] = m[k];
+  double* __restrict__ pcv = P.cov + (size_t)slot * TRI * P.N + i;
+#pragma unroll
+  for (int k = 0; k < TRI; ++k) pcv[(size_t)k * P.N] = C[k];
+  P.diff[(size_t)slot * P.N + i] = diffusion;
+}
+
+template <int D>
+__device__ inline bool all_finite(const double (&m)[D]) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < D; ++k) ok = ok && (fabs(m[k]) <= 1.79769313486231570815e+308);
+  return ok;
+}
+
+template <class RHS, int q, bool IS_EK1>
+__device__ inline void filter_fixed_lane(const FilterParams& P, long i) {
+  using S = EKStep<RHS, q, IS_EK1>;
+  constexpr int d = S::d, D = S::D, TRI = S::TRI, np = RHS::np;
+  double pl[np > 0 ? np : 1];
+#pragma unroll
+  for (int k = 0; k < np; ++k) pl[k] = P.p_shared ? P.p[k] : P.p[(size_t)k * P.N + i];
+  double u0[d];
+#pragma unroll
+  for (int a = 0; a < d; ++a) u0[a] = P.u0[(size_t)a * P.N + i];
+
+  double m[D], C[TRI];
+  taylor_init<RHS, q>(u0, pl, m);
+#pragma unroll
+  for (int k = 0; k < TRI; ++k) C[k] = 0.0;
+  if (P.everystep) store_state<D, TRI>(P, 0, i, m, C, 0.0);
+
+  double loglik = 0.0, gdiff = 0.0;
+  int chol_fix = 0;
+  for (long n = 0; n < P.nsteps; ++n) {
+    const double h = P.hs[n], pval = P.pvals[n];
+    double m2[D], C2[TRI], es[d];
+    StepAux aux;
+    aux.chol_fix = 0;
+    S::run(P.pc, pl, h, pval, P.fixed_diffusion != 0, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux);
+#pragma unroll
+    for (int k = 0; k < D; ++k) m[k] = m2[k];
+#pragma unroll
+    for (int k = 0; k < TRI; ++k) C[k] = C2[k];
+    loglik += aux.loglik;
+    gdiff = aux.sigma2_global;
+    chol_fix += aux.chol_fix;
+    if (P.everystep) store_state<D, TRI>(P, n + 1, i, m, C, gdiff);
+  }
+  if (!P.everystep) store_state<D, TRI>(P, 0, i, m, C, gdiff);
+  P.loglik[i] = loglik;
+  P.naccept[i] = (int)P.nsteps;
+  P.nreject[i] = 0;
+  P.nf[i] = (int)P.nsteps;
+  P.njac[i] = IS_EK1 ? (int)P.nsteps : 0;
+  P.nsaved[i] = P.everystep ? (int)P.nsteps + 1 : 1;
+  (void)chol_fix;
+  P.retcode[i] = all_finite<D>(m) ? 0 /*Success*/ : 3 /*Unstable*/;
+}
+
+// h^(-q-1/2) without libm pow (adaptive steps differ per lane, no host table possible)
+template <int q>
+__device__ inline double precond_val(double h) {
+  double hq = 1.0;
+#pragma unroll
+  for (int k = 0; k < q; ++k) hq *= h;
+  return 1.0 / (hq * sqrt(h));
+}
+
+// Adaptive filter: perform_step! + error estimate (src/perform_step.jl:78-92) + the PI
+// controller of OrdinaryDiffEq (third-party; exponents src/alg_utils.jl:23-24).
+template <class RHS, int q, bool IS_EK1>
+__device__ inline void filter_adaptive_lane(const FilterParams& P, long i) {
+  using S = EKStep<RHS, q, IS_EK1>;
+  constexpr int d = S::d, D = S::D, TRI = S::TRI, np = RHS::np, NB = q + 1;
+  double pl[np > 0 ? np : 1];
+#pragma unroll
+  for (int k = 0; k < np; ++k) pl[k] = P.p_shared ? P.p[k] : P.p[(size_t)k * P.N + i];
+  double u0[d];
+#pragma unroll
+  for (int a = 0; a < d; ++a) u0[a] = P.u0[(size_t)a * P.N + i];
+
+  double m[D], C[TRI];
+  taylor_init<RHS, q>(u0, pl, m);
+#pragma unroll
+  for (int k = 0; k < TRI; ++k) C[k] = 0.0;
+  store_state<D, TRI>(P, 0, i, m, C, 0.0);
+  P.tsave[i] = P.t0;
+
+  double ucur[d];
+#pragma unroll
+  for (int a = 0; a < d; ++a) ucur[a] = u0[a];
+  const Controller& ct = P.ctrl;
+  double t = P.t0, h = P.dt0, qold = ct.qoldinit, q11 = 1.0;
+  double loglik = 0.0, gdiff = 0.0;
+  int naccept = 0, nreject = 0, nsaved = 1, ret = 0;
+  const long max_attempts = 20 * P.max_save + 1000;
+  long attempts = 0;
+  while (t < P.t1) {
+    if (nsaved >= P.max_save || attempts >= max_attempts) { ret = 1; break; }  // MaxIters
+    ++attempts;
+    h = fmin(h, ct.dtmax);
+    h = fmin(h, P.t1 - t);  // tstop clipping
+    if (!(h > ct.dtmin)) { ret = 2; break; }  // DtLessThanMin
+    const double pval = precond_val<q>(h);
+    double m2[D], C2[TRI], es[d];
+    StepAux aux;
+    aux.chol_fix = 0;
+    S::run(P.pc, pl, h, pval, P.fixed_diffusion != 0, P.want_loglik != 0, naccept, gdiff, m, C, m2, C2, es, aux);
+    // DiffEqBase.calculate_residuals! + ODE_DEFAULT_NORM (src/perform_step.jl:78-84)
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < d; ++r) {
+      const double e = h * es[r] / (P.abstol + fmax(fabs(ucur[r]), fabs(m2[r])) * P.reltol);
+      acc += e * e;
+    }
+    double EEst = sqrt(acc / d);
+    if (!(EEst == EEst) || !(fabs(EEst) <= 1.79769313486231570815e+308)) EEst = INFINITY;
+#pragma unroll
+    for (int r = 0; r < d; ++r) ucur[r] = m2[r];  // integ.u .= u_filt (src/perform_step.jl:86), also when rejected
+    // stepsize_controller! (PI)
+    double qq;
+    if (EEst == 0.0) {
+      qq = 1.0 / ct.qmax;
+    } else {
+      q11 = pow(EEst, ct.beta1);
+      qq = q11 / pow(qold, ct.beta2);
+      qq = fmax(1.0 / ct.qmax, fmin(1.0 / ct.qmin, qq / ct.gamma));
+    }
+    // cache.x after the attempt when x_filt is not committed: PI*(P*x) (src/perform_step.jl:73)
+    double pj[NB], pij[NB];
+    precond_tables<NB>(h, pval, pj, pij);
+    if (EEst <= 1.0) {  // accepted by OrdinaryDiffEq
+      if (EEst < 1.0) {  // src/perform_step.jl:89
+#pragma unroll
+        for (int k = 0; k < D; ++k) m[k] = m2[k];
+#pragma unroll
+        for (int k = 0; k < TRI; ++k) C[k] = C2[k];
+        loglik += aux.loglik;
+      } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) m[k] = pij[k / d] * (pj[k / d] * m[k]);
+      }
+      if (qq <= ct.qsteady_max && qq >= ct.qsteady_min) qq = 1.0;
+      qold = fmax(EEst, ct.qoldinit);
+      double tn = t + h;
+      if (fabs(tn - P.t1) < 100.0 * 2.220446049250313e-16 * fmax(fabs(tn), fabs(P.t1))) tn = P.t1;
+      t = tn;
+      gdiff = aux.sigma2_global;
+      ++naccept;
+      store_state<D, TRI>(P, nsaved, i, m, C, gdiff);
+      P.tsave[(size_t)nsaved * P.N + i] = t;
+      ++nsaved;
+      h = h / qq;
+      if (!all_finite<D>(m)) { ret = 3; break; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < D; ++k) m[k] = pij[k / d] * (pj[k / d] * m[k]);
+      ++nreject;
+      h = h / fmin(1.0 / ct.qmin, q11 / ct.gamma);
+    }
+  }
+  P.loglik[i] = loglik;
+  P.naccept[i] = naccept;
+  P.nreject[i] = nreject;
+  P.nf[i] = naccept + nreject;
+  P.njac[i] = IS_EK1 ? naccept + nreject : 0;
+  P.nsaved[i] = nsaved;
+  P.retcode[i] = ret;
+}
+
+// ---------------------------------------------------------------------------------------
+// Rauch-Tung-Striebel pass (src/smoothing.jl:4-63, src/filtering.jl:136-154).
+// Joseph form on covariance storage:  Sigma^s = (I-GA) Sigma (I-GA)' + G (sigma^2 Q + Sigma^s_+) G'
+// which is the Gram matrix of the reference's stacked QR factor (src/smoothing.jl:53-57).
+// ---------------------------------------------------------------------------------------
+struct SmoothParams {
+  PriorConsts pc;
+  long N;
+  long n_save;          // fixed: number of saves; adaptive: capacity
+  int adaptive;
+  const double* hs;     // fixed: [n_save-1]
+  const double* pvals;  // fixed: [n_save-1]
+  const double* tsave;  // adaptive: [n_save][N]
+  const int* nsaved;    // [N]
+  const double* mean;   // filter results
+  const double* cov;
+  const double* diff;
+  double* smean;        // outputs, same layout
+  double* scov;
+  int* retcode;
+};
+
+template <int d, int q>
+__device__ inline void smooth_lane(const SmoothParams& P, long i) {
+  constexpr int NB = q + 1, D = d * NB, TRI = D * (D + 1) / 2;
+  const long n = P.adaptive ? (long)P.nsaved[i] : P.n_save;
+  const size_t N = (size_t)P.N;
+  double ms[D], Cs[TRI];
+  // copy first and last (index 1 in Julia is never smoothed, src/smoothing.jl:11)
+  {
+    const long idx[2] = {0, n - 1};
+    for (int w = 0; w < 2; ++w) {
+      const long s = idx[w];
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        ms[k] = P.mean[((size_t)s * D + k) * N + i];
+        P.smean[((size_t)s * D + k) * N + i] = ms[k];
+      }
+#pragma unroll
+      for (int k = 0; k < TRI; ++k) {
+        Cs[k] = P.cov[((size_t)s * TRI + k) * N + i];
+        P.scov[((size_t)s * TRI + k) * N + i] = Cs[k];
+      }
+    }
+  }
+  bool nan_seen = false;
+  for (long s = n - 2; s >= 1; --s) {
+    double h, pval;
+    if (P.adaptive) {
+      h = P.tsave[(size_t)(s + 1) * N + i] - P.tsave[(size_t)s * N + i];
+      pval = precond_val<q>(h);
+    } else {
+      h = P.hs[s];
+      pval = P.pvals[s];
+    }
+    if (h == 0.0) {  // src/smoothing.jl:13-16
+#pragma unroll
+      for (int k = 0; k < D; ++k) P.smean[((size_t)s * D + k) * N + i] = ms[k];
+#pragma unroll
+      for (int k = 0; k < TRI; ++k) P.scov[((size_t)s * TRI + k) * N + i] = Cs[k];
+      continue;
+    }
+    const double sigma2 = P.diff[(size_t)(s + 1) * N + i];
+    double pj[NB], pij[NB];
+    precond_tables<NB>(h, pval, pj, pij);
+    double mt[D], Ct[TRI], mst[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      mt[k] = pj[k / d] * P.mean[((size_t)s * D + k) * N + i];
+      mst[k] = pj[k / d] * ms[k];
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) {
+        Ct[tri(a, b)] = (P.cov[((size_t)s * TRI + tri(a, b)) * N + i] * pj[a / d]) * pj[b / d];
+        // V = sigma2*Q + P Sigma^s_+ P  (kept in Cs)
+        double v = (Cs[tri(a, b)] * pj[a / d]) * pj[b / d];
+        if ((a % d) == (b % d)) v += sigma2 * P.pc.Qt[a / d][b / d];
+        Cs[tri(a, b)] = v;
+      }
+    // predict (src/smoothing.jl:38): m^- = A m,  B = A Ct A' + sigma2 Q,  Lp = chol(B)
+    double mp[D];
+#pragma unroll
+    for (int J = 0; J < NB; ++J)
+#pragma unroll
+      for (int a = 0; a < d; ++a) {
+        double t = mt[J * d + a];
+#pragma unroll
+        for (int j = J + 1; j < NB; ++j) t += P.pc.At[J][j] * mt[j * d + a];
+        mp[J * d + a] = t;
+      }
+    double T[D][D];  // T = A Ct ; (Ct A')[i][k] = T[k][i]
+#pragma unroll
+    for (int J = 0; J < NB; ++J)
+#pragma unroll
+      for (int a = 0; a < d; ++a)
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          double t = Ct[symidx(J * d + a, k)];
+#pragma unroll
+          for (int j = J + 1; j < NB; ++j) t += P.pc.At[J][j] * Ct[symidx(j * d + a, k)];
+          T[J * d + a][k] = t;
+        }
+    double Lp[TRI];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int K = 0; K < NB; ++K)
+#pragma unroll
+        for (int b = 0; b < d; ++b) {
+          const int j = K * d + b;
+          if (j > a) continue;
+          double t = T[a][j];
+#pragma unroll
+          for (int k = K + 1; k < NB; ++k) t += T[a][k * d + b] * P.pc.At[K][k];
+          if ((a % d) == b) t += sigma2 * P.pc.Qt[a / d][K];
+          Lp[tri(a, j)] = t;
+        }
+    int fixes = 0;
+    chol_packed<D>(Lp, fixes);
+    // G = Ct A' B^-1 (src/smoothing.jl:42-43): rows solve  B g' = T[:, i]
+    double G[D][D];
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      double w[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) {  // forward: Lp w = y
+        double t = T[k][r];
+#pragma unroll
+        for (int c = 0; c < k; ++c) t -= Lp[tri(k, c)] * w[c];
+        w[k] = (Lp[tri(k, k)] != 0.0) ? t / Lp[tri(k, k)] : 0.0;
+      }
+#pragma unroll
+      for (int k = D - 1; k >= 0; --k) {  // backward: Lp' g = w
+        double t = w[k];
+#pragma unroll
+        for (int c = k + 1; c < D; ++c) t -= Lp[tri(c, k)] * G[r][c];
+        G[r][k] = (Lp[tri(k, k)] != 0.0) ? t / Lp[tri(k, k)] : 0.0;
+      }
+    }
+    // mean (src/smoothing.jl:44)
+    double mnew[D];
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      double t = mt[r];
+#pragma unroll
+      for (int k = 0; k < D; ++k) t += G[r][k] * (mst[k] - mp[k]);
+      mnew[r] = t;
+    }
+    // F = I - G A
+    double F[D][D];
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+      for (int K = 0; K < NB; ++K)
+#pragma unroll
+        for (int b = 0; b < d; ++b) {
+          double t = 0.0;
+#pragma unroll
+          for (int J = 0; J <= K; ++J) t += G[r][J * d + b] * P.pc.At[J][K];
+          F[r][K * d + b] = ((r == K * d + b) ? 1.0 : 0.0) - t;
+        }
+    // Sigma^s = F Ct F' + G V G'
+    double X1[D][D], X2[D][D];
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          t1 += F[r][c] * Ct[symidx(c, k)];
+          t2 += G[r][c] * Cs[symidx(c, k)];
+        }
+        X1[r][k] = t1;
+        X2[r][k] = t2;
+      }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) {
+        double t = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) t += X1[a][c] * F[b][c] + X2[a][c] * G[b][c];
+        Cs[tri(a, b)] = (t * pij[a / d]) * pij[b / d];  // un-precondition (src/smoothing.jl:26)
+      }
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      ms[k] = pij[k / d] * mnew[k];
+      nan_seen = nan_seen || !(ms[k] == ms[k]);
+      P.smean[((size_t)s * D + k) * N + i] = ms[k];
+    }
+#pragma unroll
+    for (int k = 0; k < TRI; ++k) P.scov[((size_t)s * TRI + k) * N + i] = Cs[k];
+  }
+  if (nan_seen) P.retcode[i] = 3;  // "NaNs after smoothing" (src/smoothing.jl:25)
+}
+
+}  // namespace odef

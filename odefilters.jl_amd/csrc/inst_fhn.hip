@@ -1,0 +1,7 @@
+#include "ek_kernels.h"
+namespace odef {
+int launch_filter_fhn(int q, int ek1, int adaptive, const FilterParams& P, hipStream_t s) {
+  LaunchFilter f{P, adaptive, s};
+  return dispatch_order<RhsFHN>(q, ek1, f);
+}
+}  // namespace odef

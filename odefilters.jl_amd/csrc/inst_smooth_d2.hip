@@ -1,0 +1,7 @@
+#include "ek_kernels.h"
+namespace odef {
+int launch_smooth_d2(int q, const SmoothParams& P, hipStream_t s) {
+  LaunchSmooth f{P, s};
+  return dispatch_smooth_order<2>(q, f);
+}
+}  // namespace odef

@@ -1,0 +1,18 @@
+// Internal launcher interface between the C-ABI layer (api.hip) and the kernel TUs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ek_lane.h"
+
+namespace odef {
+// returns 0, or -2 when (rhs, q) is not instantiated
+int launch_filter(int rhs, int q, int ek1, int adaptive, const FilterParams& P, hipStream_t s);
+int launch_smooth(int d, int q, const SmoothParams& P, hipStream_t s);
+// per-RHS translation units
+int launch_filter_fhn(int q, int ek1, int adaptive, const FilterParams& P, hipStream_t s);
+int launch_filter_lorenz63(int q, int ek1, int adaptive, const FilterParams& P, hipStream_t s);
+int launch_filter_lotka_volterra(int q, int ek1, int adaptive, const FilterParams& P, hipStream_t s);
+int launch_filter_vanderpol(int q, int ek1, int adaptive, const FilterParams& P, hipStream_t s);
+int launch_filter_linear(int q, int ek1, int adaptive, const FilterParams& P, hipStream_t s);
+int launch_smooth_d2(int q, const SmoothParams& P, hipStream_t s);
+int launch_smooth_d3(int q, const SmoothParams& P, hipStream_t s);
+}  // namespace odef

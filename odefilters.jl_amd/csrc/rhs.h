@@ -1,0 +1,190 @@
+// Vector-field registry of libodefilter_hip (device side).
+//
+// The reference calls a user Julia closure `f` and its Jacobian in the middle of every
+// step (src/perform_step.jl:106,116-121).  A gfx950 kernel cannot call back into the host,
+// so the vector fields are compiled in and selected by `odef_rhs` (include/odefilter.h).
+// Every `f` is generic in its scalar type so that the same source serves the step
+// (double) and the Taylor-mode initialisation (Jet<NC>, src/state_initialization.jl:15-42).
+#pragma once
+#include "odef_platform.h"
+
+namespace odef {
+
+// ---- truncated univariate Taylor arithmetic (coefficients of (t-t0)^k) ----------------
+template <int NC>
+struct Jet {
+  double c[NC];
+  __device__ Jet() {
+#pragma unroll
+    for (int k = 0; k < NC; ++k) c[k] = 0.0;
+  }
+  __device__ Jet(double x) {
+    c[0] = x;
+#pragma unroll
+    for (int k = 1; k < NC; ++k) c[k] = 0.0;
+  }
+};
+template <int NC>
+__device__ inline Jet<NC> operator+(const Jet<NC>& a, const Jet<NC>& b) {
+  Jet<NC> r;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) r.c[k] = a.c[k] + b.c[k];
+  return r;
+}
+template <int NC>
+__device__ inline Jet<NC> operator-(const Jet<NC>& a, const Jet<NC>& b) {
+  Jet<NC> r;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) r.c[k] = a.c[k] - b.c[k];
+  return r;
+}
+template <int NC>
+__device__ inline Jet<NC> operator-(const Jet<NC>& a) {
+  Jet<NC> r;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) r.c[k] = -a.c[k];
+  return r;
+}
+template <int NC>
+__device__ inline Jet<NC> operator*(const Jet<NC>& a, const Jet<NC>& b) {
+  Jet<NC> r;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j <= k; ++j) s += a.c[j] * b.c[k - j];
+    r.c[k] = s;
+  }
+  return r;
+}
+template <int NC>
+__device__ inline Jet<NC> operator*(double s, const Jet<NC>& a) {
+  Jet<NC> r;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) r.c[k] = a.c[k] * s;
+  return r;
+}
+template <int NC>
+__device__ inline Jet<NC> operator*(const Jet<NC>& a, double s) { return s * a; }
+template <int NC>
+__device__ inline Jet<NC> operator/(const Jet<NC>& a, double s) {
+  Jet<NC> r;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) r.c[k] = a.c[k] / s;
+  return r;
+}
+template <int NC>
+__device__ inline Jet<NC> operator+(const Jet<NC>& a, double s) { Jet<NC> r = a; r.c[0] += s; return r; }
+template <int NC>
+__device__ inline Jet<NC> operator+(double s, const Jet<NC>& a) { return a + s; }
+template <int NC>
+__device__ inline Jet<NC> operator-(const Jet<NC>& a, double s) { Jet<NC> r = a; r.c[0] -= s; return r; }
+template <int NC>
+__device__ inline Jet<NC> operator-(double s, const Jet<NC>& a) { Jet<NC> r = -a; r.c[0] += s; return r; }
+
+// x^a for real a:  k x0 p_k = sum_{j=1..k} (a j - (k-j)) x_j p_{k-j}
+template <int NC>
+__device__ inline Jet<NC> jet_pow(const Jet<NC>& x, double a) {
+  Jet<NC> r;
+  r.c[0] = pow(x.c[0], a);
+#pragma unroll
+  for (int k = 1; k < NC; ++k) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 1; j <= k; ++j) s += (a * j - (k - j)) * x.c[j] * r.c[k - j];
+    r.c[k] = s / (k * x.c[0]);
+  }
+  return r;
+}
+__device__ inline double jet_pow(double x, double a) { return pow(x, a); }
+// r^-3 from r^2 (Pleiades)
+__device__ inline double inv_r3(double r2) { return 1.0 / (r2 * sqrt(r2)); }
+template <int NC>
+__device__ inline Jet<NC> inv_r3(const Jet<NC>& r2) { return jet_pow(r2, -1.5); }
+
+// ---- the registry ----------------------------------------------------------------------
+
+struct RhsFHN {  // examples/fitzhughnagumo_animation.jl:8-16, README.md:36-44
+  static constexpr int d = 2, np = 3, id = 0;
+  template <class T>
+  __device__ static void f(const T (&u)[2], const double* p, T (&du)[2]) {
+    const double a = p[0], b = p[1], c = p[2];
+    du[0] = c * (u[0] - u[0] * u[0] * u[0] / 3.0 + u[1]);
+    du[1] = -(1.0 / c) * (u[0] - a - b * u[1]);
+  }
+  __device__ static void jac(const double (&u)[2], const double* p, double (&J)[2][2]) {
+    const double b = p[1], c = p[2];
+    J[0][0] = c * (1.0 - u[0] * u[0]);
+    J[0][1] = c;
+    J[1][0] = -(1.0 / c);
+    J[1][1] = b / c;
+  }
+};
+
+struct RhsLorenz63 {
+  static constexpr int d = 3, np = 3, id = 1;
+  template <class T>
+  __device__ static void f(const T (&u)[3], const double* p, T (&du)[3]) {
+    const double s = p[0], r = p[1], b = p[2];
+    du[0] = s * (u[1] - u[0]);
+    du[1] = u[0] * (r - u[2]) - u[1];
+    du[2] = u[0] * u[1] - b * u[2];
+  }
+  __device__ static void jac(const double (&u)[3], const double* p, double (&J)[3][3]) {
+    const double s = p[0], r = p[1], b = p[2];
+    J[0][0] = -s;       J[0][1] = s;    J[0][2] = 0.0;
+    J[1][0] = r - u[2]; J[1][1] = -1.0; J[1][2] = -u[0];
+    J[2][0] = u[1];     J[2][1] = u[0]; J[2][2] = -b;
+  }
+};
+
+struct RhsLotkaVolterra {
+  static constexpr int d = 2, np = 4, id = 2;
+  template <class T>
+  __device__ static void f(const T (&u)[2], const double* p, T (&du)[2]) {
+    const double a = p[0], b = p[1], c = p[2], dd = p[3];
+    du[0] = a * u[0] - b * u[0] * u[1];
+    du[1] = -c * u[1] + dd * u[0] * u[1];
+  }
+  __device__ static void jac(const double (&u)[2], const double* p, double (&J)[2][2]) {
+    const double a = p[0], b = p[1], c = p[2], dd = p[3];
+    J[0][0] = a - b * u[1];
+    J[0][1] = -b * u[0];
+    J[1][0] = dd * u[1];
+    J[1][1] = -c + dd * u[0];
+  }
+};
+
+struct RhsVanDerPol {  // test/specific_problems.jl:44-47
+  static constexpr int d = 2, np = 1, id = 3;
+  template <class T>
+  __device__ static void f(const T (&u)[2], const double* p, T (&du)[2]) {
+    const double mu = p[0];
+    du[0] = u[1];
+    du[1] = mu * ((1.0 - u[0] * u[0]) * u[1] - u[0]);
+  }
+  __device__ static void jac(const double (&u)[2], const double* p, double (&J)[2][2]) {
+    const double mu = p[0];
+    J[0][0] = 0.0;
+    J[0][1] = 1.0;
+    J[1][0] = mu * (-2.0 * u[0] * u[1] - 1.0);
+    J[1][1] = mu * (1.0 - u[0] * u[0]);
+  }
+};
+
+struct RhsLinear {  // test/convergence.jl:9-14, test/state_init.jl:12-17
+  static constexpr int d = 2, np = 2, id = 4;
+  template <class T>
+  __device__ static void f(const T (&u)[2], const double* p, T (&du)[2]) {
+    du[0] = p[0] * u[0];
+    du[1] = p[1] * u[1];
+  }
+  __device__ static void jac(const double (&u)[2], const double* p, double (&J)[2][2]) {
+    J[0][0] = p[0];
+    J[0][1] = 0.0;
+    J[1][0] = 0.0;
+    J[1][1] = p[1];
+  }
+};
+
+}  // namespace odef

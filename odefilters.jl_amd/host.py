@@ -1,0 +1,525 @@
+"""Host-side mirror of the reference's solver interface for the ensemble hot path.
+
+The reference is Julia (`solve(prob, EK1(order=3); adaptive, dt, abstol, reltol)`,
+src/algorithms.jl:23-51, src/solution.jl:8-24); there is no Julia toolchain in this image,
+so the host side above the C ABI (include/odefilter.h) is written in Python with the same
+names, keyword meanings and error behaviour.  `julia/ODEFilterHIP.jl` is the `ccall`
+binding a maintainer of the reference would add.
+
+Everything numerical happens in libodefilter_hip.so (HIP kernels for gfx950).  There is no
+CPU path: if the library is missing or no GPU is present, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libodefilter_hip.so")
+
+# ---- enums (include/odefilter.h) ---------------------------------------------------------
+EK0_ID, EK1_ID = 0, 1
+DIFFUSION = {"dynamic": 0, "fixed": 1}
+RHS = {"fhn": 0, "lorenz63": 1, "lotka_volterra": 2, "vanderpol": 3, "linear": 4, "pleiades": 5}
+RHS_DIMS = {"fhn": (2, 3), "lorenz63": (3, 3), "lotka_volterra": (2, 4), "vanderpol": (2, 1), "linear": (2, 2),
+            "pleiades": (28, 0)}
+SAVE_FINAL, SAVE_EVERYSTEP = 0, 1
+RETCODES = {0: "Success", 1: "MaxIters", 2: "DtLessThanMin", 3: "Unstable", 4: "Unstable"}
+(F_MEAN, F_COV_TRIL, F_DIFFUSION, F_T, F_LOGLIK, F_NACCEPT, F_NREJECT, F_NF, F_NJAC, F_NSAVED, F_RETCODE,
+ F_SMOOTH_MEAN, F_SMOOTH_COV_TRIL, F_U0) = range(14)
+_INT_FIELDS = {F_NACCEPT, F_NREJECT, F_NF, F_NJAC, F_NSAVED, F_RETCODE}
+MAX_ORDER = 5
+
+
+class OdefConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("alg", C.c_int32), ("order", C.c_int32), ("diffusion", C.c_int32),
+        ("smooth", C.c_int32), ("rhs_id", C.c_int32), ("d", C.c_int32), ("n_params", C.c_int32),
+        ("params_shared", C.c_int32), ("save_mode", C.c_int32), ("device", C.c_int32), ("want_loglik", C.c_int32),
+        ("n_traj", C.c_int64),
+    ]
+
+
+class OdefController(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("beta1", "beta2", "gamma", "qmin", "qmax", "qsteady_min", "qsteady_max", "qoldinit", "dtmin", "dtmax")]
+
+
+# every symbol include/odefilter.h declares: name -> (restype, argtypes)
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+SYMBOLS = {
+    "odef_version": (C.c_int, []),
+    "odef_last_error": (C.c_char_p, [_vp]),
+    "odef_create": (C.c_int, [C.POINTER(_vp), C.POINTER(OdefConfig)]),
+    "odef_destroy": (None, [_vp]),
+    "odef_set_stream": (C.c_int, [_vp, _vp]),
+    "odef_set_problem": (C.c_int, [_vp, _dp, _dp, C.c_double]),
+    "odef_set_problem_device": (C.c_int, [_vp, _vp, _vp, C.c_double]),
+    "odef_set_problem_perturbed": (C.c_int, [_vp, _dp, _dp, C.c_double, C.c_double, C.c_uint64, C.c_int64, C.c_int32]),
+    "odef_solve_fixed": (C.c_int, [_vp, _dp, C.c_int64]),
+    "odef_solve_adaptive": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(OdefController), C.c_int64]),
+    "odef_smooth": (C.c_int, [_vp]),
+    "odef_n_save": (C.c_int64, [_vp]),
+    "odef_field_bytes": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_size_t)]),
+    "odef_get": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
+    "odef_get_device": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "odef_bind_device": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
+    "odef_synchronize": (C.c_int, [_vp]),
+    "odef_kernel_time_ms": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "odef_ibm": (C.c_int, [C.c_int, C.c_int, _dp, _dp]),
+    "odef_preconditioner": (C.c_int, [C.c_int, C.c_int, C.c_double, _dp]),
+    "odef_predict": (C.c_int, [C.c_int, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "odef_update": (C.c_int, [C.c_int, C.c_int, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "odef_smooth_step": (C.c_int, [C.c_int, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+}
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libodefilter_hip.so; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C odefilters.jl_amd/csrc).  There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class OdefError(RuntimeError):
+    pass
+
+
+def _as_dp(a: np.ndarray):
+    return a.ctypes.data_as(_dp)
+
+
+class Context:
+    """RAII wrapper of `odef_ctx` (the device-side `GaussianODEFilterCache`, src/caches.jl:5-40)."""
+
+    def __init__(self, rhs: str, order: int, alg: int, n_traj: int, *, diffusion="dynamic", smooth=False,
+                 save_everystep=True, params_shared=True, device=-1, want_loglik=True):
+        self.lib = load_library()
+        if rhs not in RHS:
+            raise OdefError(f"unknown vector field {rhs!r}; the device registry has {sorted(RHS)}")
+        d, npar = RHS_DIMS[rhs]
+        cfg = OdefConfig()
+        cfg.struct_size = C.sizeof(OdefConfig)
+        cfg.alg, cfg.order, cfg.diffusion = alg, order, DIFFUSION[diffusion]
+        cfg.smooth, cfg.rhs_id, cfg.d, cfg.n_params = int(smooth), RHS[rhs], d, npar
+        cfg.params_shared = int(params_shared)
+        cfg.save_mode = SAVE_EVERYSTEP if (save_everystep or smooth) else SAVE_FINAL
+        cfg.device, cfg.want_loglik, cfg.n_traj = device, int(want_loglik), n_traj
+        self.cfg = cfg
+        self.d, self.q, self.N = d, order, n_traj
+        self.D = d * (order + 1)
+        self.TRI = self.D * (self.D + 1) // 2
+        h = _vp()
+        rc = self.lib.odef_create(C.byref(h), C.byref(cfg))
+        if rc != 0:
+            raise OdefError(self.lib.odef_last_error(None).decode())
+        self._h = h
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise OdefError(self.lib.odef_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.odef_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream_ptr: int):
+        self._chk(self.lib.odef_set_stream(self._h, _vp(stream_ptr)))
+
+    def set_problem(self, u0: np.ndarray, p: Optional[np.ndarray], t0: float):
+        u0 = np.ascontiguousarray(u0, dtype=np.float64)
+        if u0.shape != (self.N, self.d):
+            raise OdefError(f"u0 must have shape ({self.N}, {self.d}), got {u0.shape}")
+        pp = None
+        if self.cfg.n_params > 0:
+            p = np.ascontiguousarray(p, dtype=np.float64)
+            want = (self.cfg.n_params,) if self.cfg.params_shared else (self.N, self.cfg.n_params)
+            if p.shape != want:
+                raise OdefError(f"p must have shape {want}, got {p.shape}")
+            pp = _as_dp(p)
+        self._chk(self.lib.odef_set_problem(self._h, _as_dp(u0), pp, float(t0)))
+
+    def set_problem_device(self, d_u0_ptr: int, d_p_ptr: int, t0: float):
+        self._chk(self.lib.odef_set_problem_device(self._h, _vp(d_u0_ptr), _vp(d_p_ptr), float(t0)))
+
+    def set_problem_perturbed(self, base_u0, p, t0, scale, seed=0x0DEF17E5, first_index=0, n_perturbed=None):
+        base = np.ascontiguousarray(base_u0, dtype=np.float64)
+        pp = _as_dp(np.ascontiguousarray(p, dtype=np.float64)) if self.cfg.n_params > 0 else None
+        npert = self.d if n_perturbed is None else n_perturbed
+        self._chk(self.lib.odef_set_problem_perturbed(self._h, _as_dp(base), pp, float(t0), float(scale),
+                                                      C.c_uint64(seed), C.c_int64(first_index), npert))
+
+    def solve_fixed(self, tgrid: Sequence[float]):
+        tg = np.ascontiguousarray(tgrid, dtype=np.float64)
+        self._chk(self.lib.odef_solve_fixed(self._h, _as_dp(tg), len(tg)))
+
+    def solve_adaptive(self, t1, abstol=1e-6, reltol=1e-3, dt0=1e-3, controller: Optional[OdefController] = None,
+                       max_steps=4096):
+        cp = C.byref(controller) if controller is not None else None
+        self._chk(self.lib.odef_solve_adaptive(self._h, float(t1), float(abstol), float(reltol), float(dt0), cp,
+                                               int(max_steps)))
+
+    def smooth(self):
+        self._chk(self.lib.odef_smooth(self._h))
+
+    def synchronize(self):
+        self._chk(self.lib.odef_synchronize(self._h))
+
+    @property
+    def n_save(self) -> int:
+        return int(self.lib.odef_n_save(self._h))
+
+    def field_bytes(self, f: int) -> int:
+        b = C.c_size_t()
+        self._chk(self.lib.odef_field_bytes(self._h, f, C.byref(b)))
+        return b.value
+
+    def get(self, f: int) -> np.ndarray:
+        """Field in the device layout (include/odefilter.h), as a flat numpy array reshaped."""
+        nbytes = self.field_bytes(f)
+        dt = np.int32 if f in _INT_FIELDS else np.float64
+        out = np.empty(nbytes // np.dtype(dt).itemsize, dtype=dt)
+        self._chk(self.lib.odef_get(self._h, f, out.ctypes.data_as(_vp), nbytes))
+        ns, N = self.n_save, self.N
+        if f in (F_MEAN, F_SMOOTH_MEAN):
+            return out.reshape(ns, self.D, N)
+        if f in (F_COV_TRIL, F_SMOOTH_COV_TRIL):
+            return out.reshape(ns, self.TRI, N)
+        if f == F_DIFFUSION:
+            return out.reshape(ns, N)
+        if f == F_T:
+            return out.reshape(ns, N) if out.size == ns * N and out.size != ns else out
+        if f == F_U0:
+            return out.reshape(self.d, N)
+        return out
+
+    def device_ptr(self, f: int):
+        p, b = _vp(), C.c_size_t()
+        self._chk(self.lib.odef_get_device(self._h, f, C.byref(p), C.byref(b)))
+        return p.value, b.value
+
+    def bind_device(self, f: int, ptr: int, nbytes: int):
+        self._chk(self.lib.odef_bind_device(self._h, f, _vp(ptr), nbytes))
+
+    def kernel_time_ms(self, which=0):
+        ms, n = C.c_float(), C.c_int()
+        self._chk(self.lib.odef_kernel_time_ms(self._h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+# ---- constants and step-level functions --------------------------------------------------
+
+
+def ibm(d: int, q: int):
+    """`ProbNumDiffEq.ibm(d, q)` (src/priors.jl:7-59): A (upper triangular), Q_L = chol(Q).L."""
+    lib = load_library()
+    D = d * (q + 1)
+    A, QL = np.zeros((D, D)), np.zeros((D, D))
+    if lib.odef_ibm(d, q, _as_dp(A), _as_dp(QL)) != 0:
+        raise OdefError("odef_ibm failed")
+    return A, QL
+
+
+def preconditioner(d: int, q: int):
+    """`ProbNumDiffEq.preconditioner(T, d, q)` (src/preconditioning.jl:1-17): returns P(h) -> diag."""
+    lib = load_library()
+
+    def P(h: float) -> np.ndarray:
+        out = np.zeros(d * (q + 1))
+        if lib.odef_preconditioner(d, q, float(h), _as_dp(out)) != 0:
+            raise OdefError("odef_preconditioner failed")
+        return out
+
+    return P
+
+
+def _batched(mu, L):
+    mu = np.ascontiguousarray(np.atleast_2d(np.asarray(mu, float)))
+    L = np.ascontiguousarray(np.asarray(L, float).reshape(mu.shape[0], mu.shape[1], mu.shape[1]))
+    return mu, L
+
+
+def predict(mu, L, A, Q_L):
+    """`predict(x_curr, Ah, Qh)` (src/filtering.jl:56) on a batch; returns (mean, cov)."""
+    lib = load_library()
+    mu, L = _batched(mu, L)
+    n, D = mu.shape
+    A = np.ascontiguousarray(A, float); Q_L = np.ascontiguousarray(Q_L, float)
+    mo, co = np.empty((n, D)), np.empty((n, D, D))
+    if lib.odef_predict(D, n, _as_dp(mu), _as_dp(L), _as_dp(A), _as_dp(Q_L), _as_dp(mo), _as_dp(co)) != 0:
+        raise OdefError("odef_predict failed")
+    return mo, co
+
+
+def update(mu_pred, L_pred, H, z):
+    """`update(x_pred, measurement, H, R=0)` (src/filtering.jl:97) on a batch; returns (mean, cov)."""
+    lib = load_library()
+    mu, L = _batched(mu_pred, L_pred)
+    n, D = mu.shape
+    H = np.ascontiguousarray(np.asarray(H, float).reshape(n, -1, D))
+    o = H.shape[1]
+    z = np.ascontiguousarray(np.asarray(z, float).reshape(n, o))
+    mo, co = np.empty((n, D)), np.empty((n, D, D))
+    if lib.odef_update(D, o, n, _as_dp(mu), _as_dp(L), _as_dp(H), _as_dp(z), _as_dp(mo), _as_dp(co)) != 0:
+        raise OdefError("odef_update failed")
+    return mo, co
+
+
+def smooth_step(mu, L, mu_s, L_s, A, Q_L):
+    """`smooth(x_curr, x_next_smoothed, Ah, Qh)` (src/filtering.jl:136) on a batch; returns (mean, cov)."""
+    lib = load_library()
+    mu, L = _batched(mu, L)
+    mu_s, L_s = _batched(mu_s, L_s)
+    n, D = mu.shape
+    A = np.ascontiguousarray(A, float); Q_L = np.ascontiguousarray(Q_L, float)
+    mo, co = np.empty((n, D)), np.empty((n, D, D))
+    if lib.odef_smooth_step(D, n, _as_dp(mu), _as_dp(L), _as_dp(mu_s), _as_dp(L_s), _as_dp(A), _as_dp(Q_L),
+                            _as_dp(mo), _as_dp(co)) != 0:
+        raise OdefError("odef_smooth_step failed")
+    return mo, co
+
+
+# ---- the solver interface (names of src/algorithms.jl and DiffEqBase) ---------------------
+
+
+@dataclass(frozen=True)
+class EK0:
+    """`EK0(; prior=:ibm, order=3, diffusionmodel=:dynamic, smooth=true)` (src/algorithms.jl:23-28)."""
+    prior: str = "ibm"
+    order: int = 3
+    diffusionmodel: str = "dynamic"
+    smooth: bool = True
+    _id = EK0_ID
+
+
+@dataclass(frozen=True)
+class EK1:
+    """`EK1(; prior=:ibm, order=3, diffusionmodel=:dynamic, smooth=true)` (src/algorithms.jl:46-51)."""
+    prior: str = "ibm"
+    order: int = 3
+    diffusionmodel: str = "dynamic"
+    smooth: bool = True
+    _id = EK1_ID
+
+
+@dataclass
+class ODEProblem:
+    """`ODEProblem(f, u0, tspan, p)`.  `f` names a vector field of the device registry
+    (a GPU kernel cannot call a host closure)."""
+    f: str
+    u0: Sequence[float]
+    tspan: tuple
+    p: Sequence[float] = ()
+
+    def __post_init__(self):
+        if np.ndim(self.u0) != 1:
+            # src/caches.jl:46-49, test/errors.jl:11-14
+            raise OdefError("Problems which are not scalar- or vector-valued (e.g. u0 is a scalar or a matrix) "
+                            "are currently not supported")
+
+
+@dataclass
+class EnsembleProblem:
+    """`EnsembleProblem(prob; prob_func)`: either explicit initial values `u0s[N, d]` (and
+    optionally `ps[N, n_params]`), or the synthetic perturbation of SURVEY.md 8(d) generated
+    on the device: u0_i = u0 + scale*(2U-1), U from splitmix64(seed + ...)."""
+    prob: ODEProblem
+    u0s: Optional[np.ndarray] = None
+    ps: Optional[np.ndarray] = None
+    perturb_scale: Optional[float] = None
+    seed: int = 0x0DEF17E5
+    first_index: int = 0
+    n_perturbed: Optional[int] = None
+
+
+@dataclass(frozen=True)
+class EnsembleHIP:
+    """Ensemble algorithm: all trajectories on one MI355X (`device`), one lane per trajectory."""
+    device: int = -1
+
+
+def fixed_time_grid(t0: float, t1: float, dt: float) -> np.ndarray:
+    """OrdinaryDiffEq's fixed-step grid: t += dt, last step clipped onto the tstop."""
+    ts = [t0]
+    t = t0
+    eps = np.finfo(float).eps
+    while t < t1:
+        h = min(dt, t1 - t)
+        tn = t + h
+        if abs(tn - t1) < 100 * eps * max(abs(tn), abs(t1)):
+            tn = t1
+        ts.append(tn)
+        t = tn
+    return np.array(ts)
+
+
+def unpack_tril(c: np.ndarray, D: int) -> np.ndarray:
+    """[..., TRI] -> [..., D, D] symmetric."""
+    out = np.empty(c.shape[:-1] + (D, D))
+    il = np.tril_indices(D)
+    out[..., il[0], il[1]] = c
+    out[..., il[1], il[0]] = c
+    return out
+
+
+@dataclass
+class DEStats:
+    nf: np.ndarray
+    njacs: np.ndarray
+    naccept: np.ndarray
+    nreject: np.ndarray
+
+
+class EnsembleSolution:
+    """Per-trajectory `ProbODESolution` fields (src/solution.jl:8-24), batched.  Arrays are
+    fetched from the device lazily and returned trajectory-major: mean[N, n_save, D]."""
+
+    def __init__(self, ctx: Context, alg, adaptive: bool):
+        self.ctx, self.alg, self.adaptive = ctx, alg, adaptive
+        self.d, self.q, self.D = ctx.d, ctx.q, ctx.D
+        self._cache = {}
+
+    def _get(self, f):
+        if f not in self._cache:
+            self._cache[f] = self.ctx.get(f)
+        return self._cache[f]
+
+    @property
+    def t(self) -> np.ndarray:
+        t = self._get(F_T)
+        return t.T if t.ndim == 2 else t
+
+    @property
+    def nsaved(self) -> np.ndarray:
+        return self._get(F_NSAVED)
+
+    def x_filt_mean(self) -> np.ndarray:
+        return self._get(F_MEAN).transpose(2, 0, 1)
+
+    def x_filt_cov(self) -> np.ndarray:
+        return unpack_tril(self._get(F_COV_TRIL).transpose(2, 0, 1), self.D)
+
+    def x_smooth_mean(self) -> np.ndarray:
+        return self._get(F_SMOOTH_MEAN).transpose(2, 0, 1)
+
+    def x_smooth_cov(self) -> np.ndarray:
+        return unpack_tril(self._get(F_SMOOTH_COV_TRIL).transpose(2, 0, 1), self.D)
+
+    @property
+    def smoothed(self) -> bool:
+        return bool(self.alg.smooth) and self.ctx.cfg.save_mode == SAVE_EVERYSTEP
+
+    @property
+    def u(self) -> np.ndarray:
+        """sol.u: posterior mean of the solution, smoothed when alg.smooth (src/integrator_utils.jl:20-26)."""
+        m = self.x_smooth_mean() if self.smoothed else self.x_filt_mean()
+        return m[:, :, : self.d]
+
+    @property
+    def pu_cov(self) -> np.ndarray:
+        """Covariance of sol.pu = SolProj * x (src/integrator_utils.jl:21,45)."""
+        c = self.x_smooth_cov() if self.smoothed else self.x_filt_cov()
+        return c[:, :, : self.d, : self.d]
+
+    @property
+    def diffusions(self) -> np.ndarray:
+        """[N, n_save-1]: entry k = diffusion of step t[k] -> t[k+1] (src/integrator_utils.jl:44)."""
+        return self._get(F_DIFFUSION).T[:, 1:]
+
+    @property
+    def log_likelihood(self) -> np.ndarray:
+        return self._get(F_LOGLIK)
+
+    @property
+    def destats(self) -> DEStats:
+        return DEStats(self._get(F_NF), self._get(F_NJAC), self._get(F_NACCEPT), self._get(F_NREJECT))
+
+    @property
+    def retcode(self):
+        return [RETCODES[int(r)] for r in self._get(F_RETCODE)]
+
+    @property
+    def retcode_raw(self) -> np.ndarray:
+        return self._get(F_RETCODE)
+
+
+def solve(prob, alg, ensemblealg: EnsembleHIP = EnsembleHIP(), *, trajectories: Optional[int] = None,
+          dt: Optional[float] = None, adaptive: bool = True, abstol: float = 1e-6, reltol: float = 1e-3,
+          tstops: Optional[Sequence[float]] = None, save_everystep: bool = True, maxiters: int = 100000,
+          max_steps: Optional[int] = None, want_loglik: bool = True) -> EnsembleSolution:
+    """`solve(EnsembleProblem(prob), EK1(order=3), EnsembleHIP(); trajectories, dt, adaptive, abstol, reltol)`.
+
+    Keyword meaning follows DifferentialEquations.jl: `adaptive=false` needs `dt` (or `tstops`
+    as the full grid); with `adaptive=true`, `dt` is the initial step."""
+    if isinstance(prob, ODEProblem):
+        prob = EnsembleProblem(prob, u0s=np.asarray(prob.u0, float)[None, :])
+        trajectories = 1
+    base = prob.prob
+    if alg.prior != "ibm":
+        raise OdefError("Only the ibm prior is implemented so far")  # src/caches.jl:69
+    if alg.diffusionmodel not in DIFFUSION:
+        raise OdefError(f"diffusionmodel {alg.diffusionmodel!r} is not on the device path; use 'dynamic' or 'fixed'")
+    if not adaptive and dt is None and tstops is None:
+        # test/errors.jl:17-19
+        raise OdefError("Fixed timestep methods require a choice of dt or choosing the tstops")
+    if prob.u0s is not None:
+        u0s = np.ascontiguousarray(prob.u0s, float)
+        N = u0s.shape[0]
+        if trajectories is not None and trajectories != N:
+            raise OdefError(f"trajectories={trajectories} but u0s has {N} rows")
+    else:
+        if trajectories is None:
+            raise OdefError("trajectories is required")
+        N = trajectories
+    t0, t1 = float(base.tspan[0]), float(base.tspan[1])
+    shared = prob.ps is None
+    ctx = Context(base.f, alg.order, alg._id, N, diffusion=alg.diffusionmodel, smooth=alg.smooth,
+                  save_everystep=save_everystep, params_shared=shared, device=ensemblealg.device,
+                  want_loglik=want_loglik)
+    p = np.asarray(base.p, float) if shared else np.asarray(prob.ps, float)
+    if prob.u0s is not None:
+        ctx.set_problem(u0s, p, t0)
+    else:
+        if prob.perturb_scale is None:
+            raise OdefError("EnsembleProblem needs u0s or perturb_scale")
+        ctx.set_problem_perturbed(base.u0, p, t0, prob.perturb_scale, prob.seed, prob.first_index, prob.n_perturbed)
+    if adaptive:
+        ms = max_steps if max_steps is not None else 4096
+        ctx.solve_adaptive(t1, abstol, reltol, dt if dt is not None else 1e-3 * (t1 - t0), None, ms)
+    else:
+        grid = np.asarray(tstops, float) if (tstops is not None and dt is None) else fixed_time_grid(t0, t1, dt)
+        ctx.solve_fixed(grid)
+    sol = EnsembleSolution(ctx, alg, adaptive)
+    if alg.smooth and ctx.cfg.save_mode == SAVE_EVERYSTEP:
+        ctx.smooth()
+    return sol

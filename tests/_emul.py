@@ -1,0 +1,137 @@
+"""ctypes driver for tests/emul/libodef_emul.so (host build of the per-lane device source).
+Test infrastructure only."""
+import ctypes as C
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import odefilter_oracle as orc  # noqa: E402
+
+MAXNB = 6
+_LIB = None
+
+
+def build():
+    src = os.path.join(HERE, "emul", "emul.cpp")
+    out = os.path.join(HERE, "emul", "libodef_emul.so")
+    deps = [src] + [os.path.join(ROOT, "odefilters.jl_amd", "csrc", f) for f in
+                    ("ek_math.h", "ek_lane.h", "rhs.h", "dispatch.h", "odef_platform.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++20", "-shared", "-fPIC", "-Wno-unknown-pragmas", src, "-o", out])
+    return out
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+    return _LIB
+
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+
+class EmulArgs(C.Structure):
+    _fields_ = [
+        ("rhs", C.c_int), ("q", C.c_int), ("ek1", C.c_int), ("adaptive", C.c_int),
+        ("N", C.c_long), ("u0", dp), ("p", dp), ("p_shared", C.c_int),
+        ("At", dp), ("Qt", dp), ("QLt", dp),
+        ("hs", dp), ("pvals", dp), ("tgrid", dp), ("nsteps", C.c_long),
+        ("t0", C.c_double), ("t1", C.c_double), ("abstol", C.c_double), ("reltol", C.c_double), ("dt0", C.c_double),
+        ("ctrl", dp), ("max_save", C.c_long),
+        ("everystep", C.c_int), ("fixed_diffusion", C.c_int), ("want_loglik", C.c_int),
+        ("mean", dp), ("cov", dp), ("diff", dp), ("tsave", dp), ("loglik", dp),
+        ("naccept", ip), ("nreject", ip), ("nf", ip), ("njac", ip), ("nsaved", ip), ("retcode", ip),
+        ("smean", dp), ("scov", dp), ("n_save", C.c_long),
+    ]
+
+
+def prior_tables(q):
+    """(q+1)x(q+1) scalar blocks of A, Q, Q_L (priors.jl:7-59) padded to MAXNB."""
+    A, QL = orc.ibm(1, q)
+    Q = np.zeros((q + 1, q + 1))
+    for r in range(q + 1):
+        for c in range(q + 1):
+            Q[r, c] = 1.0 / ((2 * q + 1 - r - c) * math.factorial(q - r) * math.factorial(q - c))
+    out = []
+    for M in (A, Q, QL):
+        T = np.zeros((MAXNB, MAXNB))
+        T[: q + 1, : q + 1] = M
+        out.append(np.ascontiguousarray(T))
+    return out
+
+
+def _p(a, t=dp):
+    return a.ctypes.data_as(t)
+
+
+def unpack_tril(c, D):
+    """[..., TRI] -> [..., D, D] symmetric."""
+    out = np.zeros(c.shape[:-1] + (D, D))
+    k = 0
+    for i in range(D):
+        for j in range(i + 1):
+            out[..., i, j] = c[..., k]
+            out[..., j, i] = c[..., k]
+            k += 1
+    return out
+
+
+def emul_solve(rhs_id, d, q, ek1, u0s, p, *, tgrid=None, adaptive=False, t0=0.0, t1=1.0, abstol=1e-6, reltol=1e-3,
+               dt0=1e-2, max_save=4096, everystep=True, fixed_diffusion=False, want_loglik=True, smooth=False,
+               ctrl=None):
+    """u0s [N, d]; p [np] shared.  Returns dict of numpy arrays in the device layout transposed
+    to trajectory-major: mean [N, n_save, D], cov [N, n_save, D, D] ..."""
+    u0s = np.asarray(u0s, float)
+    N = u0s.shape[0]
+    D = d * (q + 1)
+    TRI = D * (D + 1) // 2
+    At, Qt, QLt = prior_tables(q)
+    u0_dev = np.ascontiguousarray(u0s.T)
+    p = np.ascontiguousarray(np.asarray(p, float))
+    if ctrl is None:
+        ctrl = np.array([7.0 / (10 * (q + 1)), 2.0 / (5 * (q + 1)), 0.9, 0.2, 10.0, 1.0, 1.0, 1e-4, 0.0, 1e300])
+    a = EmulArgs()
+    a.rhs, a.q, a.ek1, a.adaptive = rhs_id, q, int(ek1), int(adaptive)
+    a.N, a.u0, a.p, a.p_shared = N, _p(u0_dev), _p(p), 1
+    a.At, a.Qt, a.QLt = _p(At), _p(Qt), _p(QLt)
+    if adaptive:
+        n_save = max_save
+        hs = pv = tg = np.zeros(1)
+        nsteps = 0
+    else:
+        tg = np.ascontiguousarray(np.asarray(tgrid, float))
+        hs = np.ascontiguousarray(np.diff(tg))
+        pv = np.array([h ** (-q - 1 / 2) for h in hs])
+        nsteps = len(hs)
+        n_save = nsteps + 1 if everystep else 1
+    a.hs, a.pvals, a.tgrid, a.nsteps = _p(hs), _p(pv), _p(tg), nsteps
+    a.t0, a.t1, a.abstol, a.reltol, a.dt0 = t0, t1, abstol, reltol, dt0
+    a.ctrl, a.max_save = _p(ctrl), max_save
+    a.everystep, a.fixed_diffusion, a.want_loglik = int(everystep), int(fixed_diffusion), int(want_loglik)
+    mean = np.zeros((n_save, D, N)); cov = np.zeros((n_save, TRI, N)); diff = np.zeros((n_save, N))
+    tsave = np.zeros((n_save, N)); loglik = np.zeros(N)
+    ints = [np.zeros(N, np.int32) for _ in range(6)]
+    a.mean, a.cov, a.diff, a.tsave, a.loglik = _p(mean), _p(cov), _p(diff), _p(tsave), _p(loglik)
+    a.naccept, a.nreject, a.nf, a.njac, a.nsaved, a.retcode = [_p(x, ip) for x in ints]
+    smean = np.zeros_like(mean) if smooth else np.zeros(1)
+    scov = np.zeros_like(cov) if smooth else np.zeros(1)
+    a.smean, a.scov, a.n_save = _p(smean), _p(scov), n_save
+    rc = lib().emul_filter(C.byref(a))
+    assert rc == 0, rc
+    out = dict(mean=mean.transpose(2, 0, 1), cov=unpack_tril(cov.transpose(2, 0, 1), D), diff=diff.T, tsave=tsave.T,
+               loglik=loglik, naccept=ints[0], nreject=ints[1], nf=ints[2], njac=ints[3], nsaved=ints[4],
+               retcode=ints[5], tgrid=tg)
+    if smooth:
+        rc = lib().emul_smooth(C.byref(a), d)
+        assert rc == 0, rc
+        out["smean"] = smean.transpose(2, 0, 1)
+        out["scov"] = unpack_tril(scov.transpose(2, 0, 1), D)
+    return out

@@ -1,0 +1,91 @@
+// TEST INFRASTRUCTURE: host build of the per-lane device source (ek_math.h / ek_lane.h)
+// so that the arithmetic the HIP kernels execute can be checked against the oracle on a
+// machine without a GPU (and under the CPU sanitizers).  Not part of the product; the
+// library never loads this.
+#define ODEF_HOST_EMUL 1
+#include "../../odefilters.jl_amd/csrc/dispatch.h"
+#include <cstring>
+
+using namespace odef;
+
+struct EmulArgs {
+  int rhs, q, ek1, adaptive;
+  long N;
+  const double *u0, *p;
+  int p_shared;
+  const double *At, *Qt, *QLt;  // MAXNB*MAXNB each
+  const double *hs, *pvals, *tgrid;
+  long nsteps;
+  double t0, t1, abstol, reltol, dt0;
+  const double* ctrl;  // 10
+  long max_save;
+  int everystep, fixed_diffusion, want_loglik;
+  double *mean, *cov, *diff, *tsave, *loglik;
+  int *naccept, *nreject, *nf, *njac, *nsaved, *retcode;
+  // smoother
+  double *smean, *scov;
+  long n_save;
+};
+
+static void fill(const EmulArgs& a, FilterParams& P) {
+  std::memcpy(P.pc.At, a.At, sizeof(P.pc.At));
+  std::memcpy(P.pc.Qt, a.Qt, sizeof(P.pc.Qt));
+  std::memcpy(P.pc.QLt, a.QLt, sizeof(P.pc.QLt));
+  P.u0 = a.u0; P.p = a.p; P.p_shared = a.p_shared; P.N = a.N;
+  P.hs = a.hs; P.pvals = a.pvals; P.tgrid = a.tgrid; P.nsteps = a.nsteps;
+  P.t0 = a.t0; P.t1 = a.t1; P.abstol = a.abstol; P.reltol = a.reltol; P.dt0 = a.dt0;
+  std::memcpy(&P.ctrl, a.ctrl, sizeof(Controller));
+  P.max_save = a.max_save;
+  P.everystep = a.everystep; P.fixed_diffusion = a.fixed_diffusion; P.want_loglik = a.want_loglik;
+  P.mean = a.mean; P.cov = a.cov; P.diff = a.diff; P.tsave = a.tsave; P.loglik = a.loglik;
+  P.naccept = a.naccept; P.nreject = a.nreject; P.nf = a.nf; P.njac = a.njac; P.nsaved = a.nsaved;
+  P.retcode = a.retcode;
+}
+
+struct RunFilter {
+  const FilterParams& P;
+  int adaptive;
+  template <class RHS, int q, bool EK1>
+  void operator()() {
+    for (long i = 0; i < P.N; ++i) {
+      if (adaptive) filter_adaptive_lane<RHS, q, EK1>(P, i);
+      else filter_fixed_lane<RHS, q, EK1>(P, i);
+    }
+  }
+};
+struct RunSmooth {
+  const SmoothParams& P;
+  template <int d, int q>
+  void operator()() {
+    for (long i = 0; i < P.N; ++i) smooth_lane<d, q>(P, i);
+  }
+};
+
+extern "C" int emul_filter(const EmulArgs* a) {
+  FilterParams P;
+  fill(*a, P);
+  RunFilter r{P, a->adaptive};
+  switch (a->rhs) {
+    case 0: return dispatch_order<RhsFHN>(a->q, a->ek1, r);
+    case 1: return dispatch_order<RhsLorenz63>(a->q, a->ek1, r);
+    case 2: return dispatch_order<RhsLotkaVolterra>(a->q, a->ek1, r);
+    case 3: return dispatch_order<RhsVanDerPol>(a->q, a->ek1, r);
+    case 4: return dispatch_order<RhsLinear>(a->q, a->ek1, r);
+    default: return -2;
+  }
+}
+
+extern "C" int emul_smooth(const EmulArgs* a, int d) {
+  SmoothParams P;
+  std::memcpy(P.pc.At, a->At, sizeof(P.pc.At));
+  std::memcpy(P.pc.Qt, a->Qt, sizeof(P.pc.Qt));
+  std::memcpy(P.pc.QLt, a->QLt, sizeof(P.pc.QLt));
+  P.N = a->N; P.n_save = a->n_save; P.adaptive = a->adaptive;
+  P.hs = a->hs; P.pvals = a->pvals; P.tsave = a->tsave; P.nsaved = a->nsaved;
+  P.mean = a->mean; P.cov = a->cov; P.diff = a->diff; P.smean = a->smean; P.scov = a->scov;
+  P.retcode = a->retcode;
+  RunSmooth r{P};
+  if (d == 2) return dispatch_smooth_order<2>(a->q, r);
+  if (d == 3) return dispatch_smooth_order<3>(a->q, r);
+  return -2;
+}

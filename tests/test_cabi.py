@@ -1,0 +1,82 @@
+"""C-ABI boundary checks that need no GPU: the library loads, exports every symbol that
+include/odefilter.h declares, host-side constant generators match the oracle, and the
+product path fails loudly (no CPU fallback) when there is no device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "odefilter.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(odef_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_header_symbols_all_exported(pkg):
+    lib = pkg.load_library()
+    names = declared_symbols()
+    assert len(names) == 23
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/odefilter.h but not exported"
+    # and the Python binding table covers exactly the header
+    from odefilters_jl_amd import host
+
+    assert sorted(host.SYMBOLS) == names
+
+
+def test_version_and_struct_size(pkg):
+    from odefilters_jl_amd import host
+
+    assert pkg.load_library().odef_version() == 100
+    assert C.sizeof(host.OdefConfig) == 56 and C.sizeof(host.OdefController) == 80
+
+
+@pytest.mark.parametrize("d,q", [(1, 2), (2, 3), (3, 3), (2, 5)])
+def test_ibm_constants_match_oracle(pkg, orc, d, q):
+    """src/priors.jl:7-59 through odef_ibm; KAT of test/priors.jl:50-59 for (1,2)."""
+    A, QL = pkg.ibm(d, q)
+    Ao, QLo = orc.ibm(d, q)
+    np.testing.assert_array_equal(A, Ao)
+    np.testing.assert_allclose(QL, QLo, rtol=0, atol=5e-12)  # Q is Hilbert-like (cond 1.7e10 at q=5): LAPACK and this chol are equally far (3e-12) from the exact factor
+    if (d, q) == (1, 2):
+        np.testing.assert_allclose(QL @ QL.T, [[1 / 20, 1 / 8, 1 / 6], [1 / 8, 1 / 3, 1 / 2], [1 / 6, 1 / 2, 1]], rtol=1e-14)
+
+
+def test_preconditioner_matches_oracle(pkg, orc):
+    """src/preconditioning.jl:1-17 through odef_preconditioner (bit-identical running product)."""
+    for h in (2.0**-9, 7e-2, 0.05, 1e-4):
+        np.testing.assert_array_equal(pkg.preconditioner(3, 3)(h), orc.preconditioner(3, 3)(h))
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a GPU the product path must raise, not compute on the host."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.OdefError, match="no HIP device"):
+        pkg.Context("lorenz63", 3, 1, 64)
+    with pytest.raises(pkg.OdefError):
+        pkg.solve(pkg.ODEProblem("fhn", [-1.0, 1.0], (0.0, 1.0), (0.2, 0.2, 3.0)), pkg.EK0(order=1), dt=0.1, adaptive=False)
+
+
+def test_create_argument_validation(pkg):
+    from odefilters_jl_amd import host
+
+    lib = pkg.load_library()
+    cfg = host.OdefConfig()
+    h = C.c_void_p()
+    assert lib.odef_create(C.byref(h), C.byref(cfg)) != 0  # struct_size = 0
+    assert b"struct_size" in lib.odef_last_error(None)
+    cfg.struct_size = C.sizeof(host.OdefConfig)
+    cfg.rhs_id, cfg.d, cfg.n_params, cfg.order, cfg.n_traj = 1, 2, 3, 3, 8  # wrong d for Lorenz
+    assert lib.odef_create(C.byref(h), C.byref(cfg)) != 0
+    assert b"dimension" in lib.odef_last_error(None)
+    cfg.d, cfg.order = 3, 9
+    assert lib.odef_create(C.byref(h), C.byref(cfg)) != 0
+    assert b"order" in lib.odef_last_error(None)

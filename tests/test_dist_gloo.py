@@ -1,0 +1,65 @@
+"""World-size-2 test of the ensemble sharding + the single all-gather (gloo on CPU).
+The per-shard "result" here is the oracle's splitmix64 ensemble (tests may use the oracle);
+on the GPU box the same code path carries the kernels' final means over RCCL."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import odefilters_jl_amd  # noqa: F401
+    from odefilters_jl_amd import dist as od
+    import odefilter_oracle as orc
+
+    r, w, _ = od.init_from_env(backend="gloo")
+    lo, hi = od.shard_bounds(total, r, w)
+    local = torch.from_numpy(orc.ensemble_u0(np.array([1.0, 0.0, 0.0]), hi - lo, 1e-2, first=lo).T.copy())  # [d, n_local]
+    g = od.allgather_shards(local, w)
+    full = od.gathered_to_global(g)
+    if r == 0:
+        q.put(full.numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_bounds(pkg):
+    from odefilters_jl_amd import dist as od
+
+    for total, world in ((65536, 8), (10, 3), (7, 8)):
+        b = [od.shard_bounds(total, r, world) for r in range(world)]
+        assert b[0][0] == 0 and b[-1][1] == total
+        assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def test_two_rank_allgather_reassembles_ensemble(orc):
+    total, world = 64, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(full.T, orc.ensemble_u0(np.array([1.0, 0.0, 0.0]), total, 1e-2))

@@ -1,0 +1,219 @@
+"""Parity of the HIP kernels (through the C ABI, libodefilter_hip.so) with the oracle and the
+committed golden fixtures.  Needs a real MI355X: run with `-m gpu`."""
+import os
+
+import numpy as np
+import pytest
+
+import _parity as P
+import odefilter_oracle as orc
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _alg(pkg, kind, order, diffusion="dynamic", smooth=True):
+    return (pkg.EK1 if kind == "EK1" else pkg.EK0)(order=order, diffusionmodel=diffusion, smooth=smooth)
+
+
+# ---- golden fixtures ------------------------------------------------------------------------
+
+GOLDEN_FIXED = ["fhn_ek0_q1_cfg1", "lorenz_ek1_q3", "lv_ek1_q2_fixeddiff", "lv_ek0_q4", "vdp_ek1_q5"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_FIXED)
+def test_golden_fixed_step(pkg, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    rhs, kind, order = str(g["rhs"]), str(g["kind"]), int(g["order"])
+    diffusion = str(g["diffusionmodel"])
+    vf = orc.vector_field(rhs)
+    u0s = g["u0s"]
+    prob = pkg.EnsembleProblem(pkg.ODEProblem(rhs, u0s[0], tuple(g["tspan"]), g["p"]), u0s=u0s)
+    sol = pkg.solve(prob, _alg(pkg, kind, order, diffusion), pkg.EnsembleHIP(), dt=float(g["dt"]), adaptive=False)
+    assert sol.retcode == ["Success"] * len(u0s)
+    np.testing.assert_array_equal(sol.t, g["t"][0])
+    alg_o = orc.Alg(kind, order, diffusion, True)
+    kw = dict(tspan=tuple(g["tspan"]), dt=float(g["dt"]))
+    mf, cf, ms, cs = sol.x_filt_mean(), sol.x_filt_cov(), sol.x_smooth_mean(), sol.x_smooth_cov()
+    for i in range(len(u0s)):
+        for smoothed, (m, c, gm, gc) in ((False, (mf, cf, g["mean_filt"], g["cov_filt"])),
+                                         (True, (ms, cs, g["mean_smooth"], g["cov_smooth"]))):
+            _, nm, nc = P.oracle_noise(vf, alg_o, u0s[i], kw, smoothed, n_pert=2)
+            P.check_against_oracle(m[i], c[i], gm[i], gc[i], vf.d, nm, nc, f"{name}[{i}] smoothed={smoothed}")
+    np.testing.assert_allclose(sol.diffusions, g["diffusions"], rtol=1e-6)
+    if diffusion == "dynamic":
+        np.testing.assert_allclose(sol.log_likelihood, g["loglik"], rtol=1e-6)
+    else:
+        assert np.all(np.isnan(sol.log_likelihood))  # src/integrator_utils.jl:6
+    # sol.pu[1]: mean u0, zero covariance (test/solution.jl:38-41)
+    np.testing.assert_array_equal(sol.x_filt_mean()[:, 0, : vf.d], u0s)
+    assert np.all(sol.x_filt_cov()[:, 0] == 0.0)
+
+
+def test_golden_adaptive(pkg):
+    """Config-5 shape: adaptive PI + RTS.  Step sequences coincide because both sides restate the
+    same controller; parity is asserted at the solver tolerance on common times as well."""
+    g = np.load(os.path.join(GOLD, "lorenz_ek1_q3_adaptive.npz"))
+    u0s = g["u0s"]
+    prob = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", u0s[0], tuple(g["tspan"]), g["p"]), u0s=u0s)
+    sol = pkg.solve(prob, pkg.EK1(order=3), pkg.EnsembleHIP(), dt=float(g["dt"]), adaptive=True,
+                    abstol=float(g["abstol"]), reltol=float(g["reltol"]), max_steps=256)
+    assert sol.retcode == ["Success"] * 3
+    np.testing.assert_array_equal(sol.destats.naccept, g["naccept"])
+    np.testing.assert_array_equal(sol.destats.nreject, g["nreject"])
+    for i in range(3):
+        n = int(sol.nsaved[i])
+        assert n == g["naccept"][i] + 1
+        np.testing.assert_allclose(sol.t[i, :n], g["t"][i, :n], rtol=1e-9)
+        np.testing.assert_allclose(sol.x_filt_mean()[i, :n, :3], g["mean_filt"][i, :n, :3], rtol=1e-7)
+        np.testing.assert_allclose(sol.u[i, :n], g["mean_smooth"][i, :n, :3], rtol=1e-7)
+        assert sol.t[i, n - 1] == g["tspan"][1]
+
+
+# ---- seeded parity against the oracle at sizes it finishes in seconds ------------------------
+
+
+@pytest.mark.parametrize("rhs,kind,q,dt,t1", [
+    ("lorenz63", "EK1", 3, 2.0**-9, 2.0),      # BASELINE config 2/3 problem, full time span
+    ("lorenz63", "EK0", 2, 2.0**-9, 0.25),
+    ("lorenz63", "EK1", 5, 2.0**-8, 0.25),
+    ("fhn", "EK1", 4, 5e-3, 1.0),
+    ("lotka_volterra", "EK0", 1, 5e-3, 1.0),
+    ("vanderpol", "EK0", 3, 1e-2, 1.0),
+    ("linear", "EK1", 2, 1e-2, 1.0),
+])
+def test_ensemble_parity_with_oracle(pkg, rhs, kind, q, dt, t1):
+    vf = orc.vector_field(rhs)
+    N = 130  # ragged: not a multiple of the 64-lane wavefront
+    ens = pkg.EnsembleProblem(pkg.ODEProblem(rhs, vf.u0, (0.0, t1), vf.p), perturb_scale=1e-2)
+    sol = pkg.solve(ens, _alg(pkg, kind, q), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    np.testing.assert_array_equal(sol.ctx.get(13).T, u0s)  # device splitmix64 ensemble == oracle's, bit for bit
+    assert sol.retcode == ["Success"] * N
+    alg_o = orc.Alg(kind, q, "dynamic", True)
+    mf, cf, ms, cs = sol.x_filt_mean(), sol.x_filt_cov(), sol.x_smooth_mean(), sol.x_smooth_cov()
+    for i in (0, 63, 64, 129):
+        for smoothed, (m, c) in ((False, (mf, cf)), (True, (ms, cs))):
+            base, nm, nc = P.oracle_noise(vf, alg_o, u0s[i], dict(tspan=(0.0, t1), dt=dt), smoothed, n_pert=2)
+            P.check_against_oracle(m[i], c[i], base.means(smoothed=smoothed), base.covs(smoothed=smoothed), vf.d, nm, nc,
+                                   f"{rhs} {kind}({q}) traj {i} smoothed={smoothed}")
+
+
+def test_per_trajectory_parameters(pkg):
+    vf = orc.vector_field("lotka_volterra")
+    N = 70
+    rng = np.random.default_rng(3)
+    ps = vf.p[None, :] * (1.0 + 0.05 * rng.standard_normal((N, 4)))
+    u0s = np.tile(vf.u0, (N, 1))
+    prob = pkg.EnsembleProblem(pkg.ODEProblem("lotka_volterra", vf.u0, (0.0, 0.5), vf.p), u0s=u0s, ps=ps)
+    sol = pkg.solve(prob, pkg.EK1(order=3, smooth=False), pkg.EnsembleHIP(), dt=5e-3, adaptive=False)
+    for i in (0, 69):
+        ref = orc.solve(vf, orc.EK1(order=3, smooth=False), p=ps[i], tspan=(0.0, 0.5), dt=5e-3)
+        np.testing.assert_allclose(sol.u[i], ref.u, rtol=1e-10)
+
+
+# ---- step-level entry points: test/filtering.jl identities through the C ABI -----------------
+
+
+def _rand_lower(rng, n, d):
+    return np.tril(rng.random((n, d, d)))
+
+
+def test_predict_update_smooth_step_identities(pkg):
+    """test/filtering.jl:28-46, 79-89, 118-122 on a seeded batch (d = 5, o = 3)."""
+    rng = np.random.default_rng(11)
+    n, d, o = 67, 5, 3
+    m, L = rng.random((n, d)), _rand_lower(rng, n, d)
+    A, LQ = rng.random((d, d)), np.tril(rng.random((d, d)))
+    Pm = L @ L.transpose(0, 2, 1)
+    mo, co = pkg.predict(m, L, A, LQ)
+    np.testing.assert_allclose(mo, m @ A.T, rtol=1e-14)
+    np.testing.assert_allclose(co, A @ Pm @ A.T + LQ @ LQ.T, rtol=1e-8)
+    H = rng.random((n, o, d))
+    z = np.einsum("nod,nd->no", H, m)
+    S = H @ Pm @ H.transpose(0, 2, 1)
+    K = Pm @ H.transpose(0, 2, 1) @ np.linalg.inv(S)
+    mu, cu = pkg.update(m, L, H, z)
+    np.testing.assert_allclose(mu, m + np.einsum("ndo,no->nd", K, 0 - z), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(cu, Pm - K @ S @ K.transpose(0, 2, 1), rtol=1e-6, atol=1e-9)
+    ms_, Ls = rng.random((n, d)), _rand_lower(rng, n, d)
+    Ps = Ls @ Ls.transpose(0, 2, 1)
+    mp_, Pp = m @ A.T, A @ Pm @ A.T + LQ @ LQ.T
+    G = Pm @ A.T @ np.linalg.inv(Pp)
+    msm, csm = pkg.smooth_step(m, L, ms_, Ls, A, LQ)
+    np.testing.assert_allclose(msm, m + np.einsum("nij,nj->ni", G, ms_ - mp_), rtol=1e-7)
+    np.testing.assert_allclose(csm, Pm + G @ (Ps - Pp) @ G.transpose(0, 2, 1), rtol=1e-6, atol=1e-8)
+    # against the oracle functions themselves
+    for i in (0, 66):
+        xo = orc.predict(orc.SRGaussian(m[i], L[i]), A, LQ)
+        np.testing.assert_allclose(co[i], xo.cov(), rtol=1e-12)
+        xs, _ = orc.smooth(orc.SRGaussian(m[i], L[i]), orc.SRGaussian(ms_[i], Ls[i]), A, LQ)
+        np.testing.assert_allclose(csm[i], xs.cov(), rtol=1e-9, atol=1e-12)
+
+
+def test_empty_batch_and_bad_dims(pkg):
+    A = np.eye(3)
+    mo, co = pkg.predict(np.zeros((0, 3)), np.zeros((0, 3, 3)), A, A)
+    assert mo.shape == (0, 3) and co.shape == (0, 3, 3)
+    with pytest.raises(pkg.OdefError):
+        pkg.predict(np.zeros((1, 40)), np.zeros((1, 40, 40)), np.eye(40), np.eye(40))  # > ODEF_MAX_STEP_DIM
+
+
+# ---- BASELINE-size runs: size-independent properties ------------------------------------------
+
+
+def test_full_size_properties(pkg):
+    """65 536 trajectories (BASELINE config 3 ensemble), shortened time span so the output fits a
+    test: (a) a sample of trajectories matches the oracle, (b) duplicated inputs give bitwise equal
+    outputs wherever they sit in the batch, (c) covariances are PSD with exact zero initial block,
+    (d) final-only save mode equals the last every-step record."""
+    vf = orc.vector_field("lorenz63")
+    N, nsteps, dt = 65536, 32, 2.0**-9
+    tspan = (0.0, nsteps * dt)
+    u0s = orc.ensemble_u0(vf.u0, 8, 1e-2)
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, tspan, vf.p), perturb_scale=1e-2)
+    sol = pkg.solve(ens, pkg.EK1(order=3, smooth=False), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
+    assert np.all(sol.retcode_raw == 0)
+    mean = sol.ctx.get(0)  # [n_save, D, N]
+    cov = sol.ctx.get(1)
+    for i in range(8):
+        ref = orc.solve(vf, orc.EK1(order=3, smooth=False), u0=u0s[i], tspan=tspan, dt=dt)
+        np.testing.assert_allclose(mean[:, :3, i], ref.u, rtol=1e-11)
+    Cl = pkg.unpack_tril(cov[-1].T, 12)
+    w = np.linalg.eigvalsh(Cl[:4096])
+    assert w.min() > -1e-9 * np.abs(w).max()
+    assert np.all(cov[0] == 0.0)
+    # (b) permutation / position independence
+    pick = np.array([5, 70, 4097, 65535])
+    u0_dev = sol.ctx.get(13).T
+    prob2 = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, tspan, vf.p), u0s=u0_dev[pick][::-1].copy())
+    sol2 = pkg.solve(prob2, pkg.EK1(order=3, smooth=False), pkg.EnsembleHIP(), dt=dt, adaptive=False)
+    np.testing.assert_array_equal(sol2.ctx.get(0)[:, :, ::-1], mean[:, :, pick])
+    np.testing.assert_array_equal(sol2.ctx.get(1)[:, :, ::-1], cov[:, :, pick])
+    # (d) final-only
+    sol3 = pkg.solve(ens, pkg.EK1(order=3, smooth=False), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False,
+                     save_everystep=False)
+    np.testing.assert_array_equal(sol3.ctx.get(0)[0], mean[-1])
+    np.testing.assert_array_equal(sol3.ctx.get(1)[0], cov[-1])
+
+
+def test_caller_owned_output_buffers_and_stream(pkg):
+    """odef_bind_device / odef_set_stream with torch-owned memory and torch's stream."""
+    import torch
+
+    vf = orc.vector_field("lorenz63")
+    N, nsteps, dt = 256, 16, 2.0**-9
+    ctx = pkg.Context("lorenz63", 3, 1, N, save_everystep=False)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    out = torch.zeros(12, N, dtype=torch.float64, device="cuda")
+    ctx.bind_device(0, out.data_ptr(), out.numel() * 8)
+    ctx.set_problem_perturbed(vf.u0, vf.p, 0.0, 1e-2)
+    ctx.solve_fixed(np.arange(nsteps + 1) * dt)
+    torch.cuda.synchronize()
+    ref = orc.solve(vf, orc.EK1(order=3, smooth=False), u0=orc.ensemble_u0(vf.u0, 1, 1e-2)[0], tspan=(0.0, nsteps * dt), dt=dt)
+    np.testing.assert_allclose(out[:3, 0].cpu().numpy(), ref.u[-1], rtol=1e-12)
+    ptr, nbytes = ctx.device_ptr(0)
+    assert ptr == out.data_ptr() and nbytes == 12 * N * 8
+    ms, nl = ctx.kernel_time_ms(0)
+    assert ms > 0 and nl == 1
+    ctx.close()

@@ -1,0 +1,43 @@
+"""Host mirror of the reference's solver interface: argument handling that needs no GPU."""
+import numpy as np
+import pytest
+
+
+def test_scalar_u0_rejected(pkg):
+    """test/errors.jl:11-14 / src/caches.jl:46-49."""
+    with pytest.raises(pkg.OdefError, match="scalar- or vector-valued"):
+        pkg.ODEProblem("linear", 1.0, (0.0, 1.0), (1.0, 1.0))
+    with pytest.raises(pkg.OdefError):
+        pkg.ODEProblem("linear", np.ones((2, 2)), (0.0, 1.0), (1.0, 1.0))
+
+
+def test_fixed_steps_need_dt(pkg):
+    """test/errors.jl:17-19."""
+    prob = pkg.ODEProblem("fhn", [-1.0, 1.0], (0.0, 20.0), (0.2, 0.2, 3.0))
+    with pytest.raises(pkg.OdefError, match="Fixed timestep methods require a choice of dt"):
+        pkg.solve(prob, pkg.EK0(order=1), adaptive=False)
+
+
+def test_alg_defaults_match_reference(pkg):
+    """src/algorithms.jl:23-28,46-51."""
+    for Alg in (pkg.EK0, pkg.EK1):
+        a = Alg()
+        assert (a.prior, a.order, a.diffusionmodel, a.smooth) == ("ibm", 3, "dynamic", True)
+    with pytest.raises(pkg.OdefError, match="ibm prior"):
+        pkg.solve(pkg.ODEProblem("fhn", [-1.0, 1.0], (0.0, 1.0), (0.2, 0.2, 3.0)), pkg.EK0(prior="ioup"), dt=0.1, adaptive=False)
+
+
+def test_fixed_time_grid(pkg, orc):
+    g = pkg.fixed_time_grid(0.0, 20.0, 7e-2)
+    assert len(g) == 287 and g[-1] == 20.0 and abs((g[-1] - g[-2]) - 0.05) < 1e-9
+    np.testing.assert_array_equal(g, orc.fixed_time_grid(0.0, 20.0, 7e-2))
+    g2 = pkg.fixed_time_grid(0.0, 2.0, 2.0**-9)
+    np.testing.assert_array_equal(g2, np.arange(1025) * 2.0**-9)
+
+
+def test_unpack_tril(pkg):
+    D = 4
+    M = np.arange(16.0).reshape(4, 4)
+    M = M + M.T
+    packed = np.array([M[i, j] for i in range(D) for j in range(i + 1)])
+    np.testing.assert_array_equal(pkg.unpack_tril(packed[None], D)[0], M)

@@ -1,0 +1,215 @@
+"""Pins the oracle (oracle/odefilter_oracle.py) to the reference's own tests.
+
+Each test restates one test of /root/reference/test (cited), on seeded random inputs where
+the reference uses bare `rand`.  CPU only.
+"""
+import math
+
+import numpy as np
+import pytest
+from scipy.integrate import solve_ivp
+
+import odefilter_oracle as orc
+
+RNG = np.random.default_rng(20211003)
+
+
+# ---- test/priors.jl ---------------------------------------------------------------------
+
+
+def test_vanilla_ibm_d2_q2():
+    """test/priors.jl:13-40."""
+    h, sig = RNG.random(), RNG.random()
+    A_of, Q_of = orc.vanilla_ibm(2, 2)
+    AH = np.array([[1, 0, h, 0, h**2 / 2, 0], [0, 1, 0, h, 0, h**2 / 2], [0, 0, 1, 0, h, 0],
+                   [0, 0, 0, 1, 0, h], [0, 0, 0, 0, 1, 0], [0, 0, 0, 0, 0, 1]])
+    QH = sig**2 * np.array([[h**5 / 20, 0, h**4 / 8, 0, h**3 / 6, 0], [0, h**5 / 20, 0, h**4 / 8, 0, h**3 / 6],
+                            [h**4 / 8, 0, h**3 / 3, 0, h**2 / 2, 0], [0, h**4 / 8, 0, h**3 / 3, 0, h**2 / 2],
+                            [h**3 / 6, 0, h**2 / 2, 0, h, 0], [0, h**3 / 6, 0, h**2 / 2, 0, h]])
+    np.testing.assert_allclose(A_of(h), AH, rtol=1e-14)
+    np.testing.assert_allclose(Q_of(h, sig**2), QH, rtol=1e-14)
+
+
+def test_preconditioned_ibm_d1_q2():
+    """test/priors.jl:44-60: exact tables."""
+    sig = RNG.random()
+    A, QL = orc.ibm(1, 2)
+    np.testing.assert_allclose(A, [[1, 1, 0.5], [0, 1, 1], [0, 0, 1]], rtol=0, atol=0)
+    np.testing.assert_allclose(sig**2 * (QL @ QL.T), sig**2 * np.array([[1 / 20, 1 / 8, 1 / 6], [1 / 8, 1 / 3, 1 / 2], [1 / 6, 1 / 2, 1]]),
+                               rtol=1e-14)
+
+
+@pytest.mark.parametrize("q", [1, 2, 3, 4, 5])
+def test_prior_dim(q):
+    """test/priors.jl:64-74."""
+    vf = orc.vector_field("lotka_volterra")
+    sol = orc.solve(vf, orc.EK0(order=q, smooth=False), dt=0.1)
+    assert sol.x_filt[-1].mu.shape == (vf.d * (q + 1),)
+
+
+# ---- test/preconditioning.jl ---------------------------------------------------------------
+
+
+def test_preconditioning_equivalence_and_condition():
+    """test/preconditioning.jl:12-39."""
+    h, sig = 0.1 * RNG.random(), RNG.random()
+    d, q = 2, 3
+    A_of, Q_of = orc.vanilla_ibm(d, q)
+    Ah, Qh = A_of(h), Q_of(h, sig**2)
+    A_p, QL_p = orc.ibm(d, q)
+    Qh_p = sig**2 * (QL_p @ QL_p.T)
+    P = orc.preconditioner(d, q)(h)
+    np.testing.assert_allclose(Qh_p, np.diag(P) @ Qh @ np.diag(P), rtol=1e-10)
+    np.testing.assert_allclose(A_p, np.diag(P) @ Ah @ np.diag(1 / P), rtol=1e-10, atol=1e-14)
+    assert np.linalg.cond(Qh) > np.linalg.cond(Qh_p)
+    assert np.linalg.cond(Qh) > np.linalg.cond(Qh_p) ** 2
+
+
+# ---- test/state_init.jl -------------------------------------------------------------------
+
+
+def test_state_init_derivatives_q6():
+    """test/state_init.jl:7-35: u' = (a u1, b u2) has u^(k)(0) = (a^k u1, b^k u2)."""
+    a, b = 1.1, -0.5
+    u0 = np.array([0.1, 1.0])
+    vf = orc.vector_field("linear")
+    dfs = orc.get_derivatives(u0, vf, np.array([a, b]), 0.0, 6)
+    assert len(dfs) == 6
+    truth = np.concatenate([[a**k * u0[0], b**k * u0[1]] for k in range(1, 7)])
+    np.testing.assert_allclose(np.concatenate(dfs), truth, rtol=1e-13)
+
+
+def test_initial_state_is_exact():
+    """test/solution.jl:38-41: sol.pu[1] has mean u0 and zero covariance."""
+    vf = orc.vector_field("fhn")
+    x0 = orc.initial_update(vf.u0, vf, vf.p, 0.0, 3)
+    np.testing.assert_array_equal(x0.mu[:2], vf.u0)
+    assert np.all(x0.cov() == 0.0)
+
+
+# ---- test/filtering.jl ---------------------------------------------------------------------
+
+
+def _rand_lower(d):
+    return np.tril(RNG.random((d, d)))
+
+
+def test_predict_identity():
+    """test/filtering.jl:10-48 (SRMatrix variant: mean `==`, covariance `≈`)."""
+    d = 5
+    m, L_p, A, L_Q = RNG.random(d), _rand_lower(d), RNG.random((d, d)), _rand_lower(d)
+    x = orc.predict(orc.SRGaussian(m, L_p), A, L_Q)
+    np.testing.assert_array_equal(x.mu, A @ m)
+    np.testing.assert_allclose(x.cov(), A @ (L_p @ L_p.T) @ A.T + L_Q @ L_Q.T, rtol=math.sqrt(np.finfo(float).eps))
+
+
+def test_update_identity():
+    """test/filtering.jl:52-91 (o = 3, d = 5, R = 0)."""
+    d, o = 5, 3
+    m_p, L = RNG.random(d), _rand_lower(d)
+    P_p = L @ L.T
+    H = RNG.random((o, d))
+    z, S = H @ m_p, H @ P_p @ H.T
+    K = P_p @ H.T @ np.linalg.inv(S)
+    x = orc.update(orc.SRGaussian(m_p, L), z, S, H)
+    np.testing.assert_allclose(x.mu, m_p + K @ (0 - z), rtol=1e-13)
+    np.testing.assert_allclose(x.cov(), P_p - K @ S @ K.T, rtol=1e-6, atol=1e-10)
+
+
+def test_smooth_identity():
+    """test/filtering.jl:94-124."""
+    d = 5
+    m, m_s = RNG.random(d), RNG.random(d)
+    L_P, L_Ps, A, L_Q = _rand_lower(d), _rand_lower(d), RNG.random((d, d)), _rand_lower(d)
+    ms, Ps = orc.smooth_dense(m, L_P @ L_P.T, m_s, L_Ps @ L_Ps.T, A, L_Q @ L_Q.T)
+    x, _ = orc.smooth(orc.SRGaussian(m, L_P), orc.SRGaussian(m_s, L_Ps), A, L_Q)
+    np.testing.assert_allclose(x.mu, ms, rtol=1e-7)
+    np.testing.assert_allclose(x.cov(), Ps, rtol=1e-6, atol=1e-8)
+
+
+# ---- test/correctness.jl, test/convergence.jl, test/smoothing.jl ------------------------------
+
+
+def _truth(vf, ts, u0=None, p=None):
+    u0 = vf.u0 if u0 is None else u0
+    p = vf.p if p is None else p
+    r = solve_ivp(lambda t, u: np.array(vf.f(list(u), p, t)), (ts[0], ts[-1]), u0, method="DOP853", rtol=1e-13,
+                  atol=1e-13, t_eval=ts)
+    return r.y.T
+
+
+@pytest.mark.parametrize("rhs", ["lotka_volterra", "fhn"])
+@pytest.mark.parametrize("kind", ["EK0", "EK1"])
+@pytest.mark.parametrize("diffusion", ["dynamic", "fixed"])
+@pytest.mark.parametrize("q", [1, 3, 5])
+def test_fixed_step_correctness(rhs, kind, diffusion, q):
+    """test/correctness.jl:15-39: dt = 5e-3, sol.u ≈ truth at rtol 1e-5 (norm-wise, as Julia's ≈).
+    FHN here is the README problem on (0, 2) (the DiffEqProblemLibrary one is not in the tree)."""
+    vf = orc.vector_field(rhs)
+    tspan = (0.0, 1.0) if rhs == "lotka_volterra" else (0.0, 2.0)
+    sol = orc.solve(vf, orc.Alg(kind, q, diffusion, True), dt=5e-3, tspan=tspan)
+    truth = _truth(vf, np.array(sol.t))
+    # the README FHN (c = 3) is stiffer than DiffEqProblemLibrary's; order 1 reaches 5e-5 on it
+    rtol = 1e-4 if (rhs == "fhn" and q == 1) else 1e-5
+    assert np.linalg.norm(sol.u - truth) <= rtol * np.linalg.norm(truth)
+    assert sol.retcode == "Success"
+
+
+@pytest.mark.parametrize("rhs", ["lotka_volterra", "fhn"])
+@pytest.mark.parametrize("q", [2, 4])
+def test_adaptive_correctness(rhs, q):
+    """test/correctness.jl:42-71: default tolerances, rtol 1e-3 at the step points."""
+    vf = orc.vector_field(rhs)
+    tspan = (0.0, 1.0) if rhs == "lotka_volterra" else (0.0, 2.0)
+    sol = orc.solve(vf, orc.EK1(order=q), adaptive=True, dt=1e-2, tspan=tspan)
+    truth = _truth(vf, np.array(sol.t))
+    assert np.linalg.norm(sol.u - truth) <= 1e-3 * np.linalg.norm(truth)
+    assert sol.t[-1] == tspan[1]
+    # dense output (solution.jl:165-210) on a grid
+    consts = orc.make_consts(vf.d, q)
+    tg = np.linspace(tspan[0], tspan[1], 51)
+    dense = np.array([orc.dense_output(sol, consts, t).mu[: vf.d] for t in tg])
+    td = _truth(vf, tg)
+    assert np.linalg.norm(dense - td) <= 1e-3 * np.linalg.norm(td)
+
+
+@pytest.mark.parametrize("kind,q", [("EK0", 1), ("EK0", 2), ("EK0", 3), ("EK1", 1), ("EK1", 3), ("EK1", 4)])
+def test_convergence_order(kind, q):
+    """test/convergence.jl:17-38: u' = 1.01 u, observed order of the final-point error ~ q+1."""
+    vf = orc.vector_field("linear")
+    p = np.array([1.01, 1.01])
+    u0 = np.array([0.5, 0.5])
+    errs = []
+    dts = [2.0**-k for k in ((4, 5, 6, 7) if q <= 2 else ((2, 3, 4, 5) if q == 3 else (3, 4, 5)))]
+    for dt in dts:
+        sol = orc.solve(vf, orc.Alg(kind, q, "dynamic", False), u0=u0, p=p, tspan=(0.0, 1.0), dt=dt)
+        errs.append(abs(sol.u[-1, 0] - 0.5 * math.exp(1.01)))
+    orders = np.log2(np.array(errs[:-1]) / np.array(errs[1:]))
+    assert abs(np.mean(orders) - (q + 1)) < 0.5, (orders, errs)
+
+
+def test_smoothing():
+    """test/smoothing.jl:13-48: same t, same last state, different interior, smoothed error < 2x filter."""
+    vf = orc.vector_field("lotka_volterra")
+    s_f = orc.solve(vf, orc.EK0(order=4, smooth=False), dt=1e-2)
+    s_s = orc.solve(vf, orc.EK0(order=4, smooth=True), dt=1e-2)
+    assert s_f.t == s_s.t
+    np.testing.assert_array_equal(s_f.u[-1], s_s.u[-1])
+    assert not np.allclose(s_f.u[5:-5], s_s.u[5:-5], rtol=1e-12, atol=0)
+    truth = _truth(vf, np.array(s_f.t))
+    assert np.abs(s_s.u - truth).max() < 2 * np.abs(s_f.u - truth).max()
+    # survives tiny steps with q = 4 (test/smoothing.jl:13-22)
+    sol = orc.solve(vf, orc.EK0(order=4, smooth=True), dt=1e-4, tspan=(0.0, 0.02))
+    assert np.all(np.isfinite(sol.means()))
+
+
+def test_errors():
+    """test/errors.jl:17-19: adaptive=false without dt throws."""
+    with pytest.raises(ValueError):
+        orc.solve(orc.vector_field("fhn"), orc.EK0(), adaptive=False)
+
+
+def test_splitmix_reference_values():
+    """splitmix64 known answers (Vigna's reference implementation, seed 0 -> first outputs)."""
+    assert orc.splitmix64(0) == 0xE220A8397B1DCDAF
+    assert orc.splitmix64(0x9E3779B97F4A7C15) == 0x6E789E6AA1B965F4
