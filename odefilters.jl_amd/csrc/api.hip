@@ -184,9 +184,13 @@ __global__ void perturbed_u0_kernel(PerturbArgs a, double* __restrict__ dst /*[d
   for (int k = 0; k < d; ++k) {
     double v = a.base[k];
     if (k < n_pert) {
+#pragma clang fp contract(off)
       const unsigned long long r = splitmix64(seed + (unsigned long long)n_pert * (unsigned long long)(first + i) + k);
       const double U = (double)(r >> 11) * 0x1.0p-53;
-      v = a.base[k] + scale * (2.0 * U - 1.0);
+      // separate roundings (no FMA contraction) so that the ensemble is bit-identical to the host generators
+      const double w = 2.0 * U - 1.0;
+      const double sw = scale * w;
+      v = a.base[k] + sw;
     }
     dst[(size_t)k * N + i] = v;
   }
