@@ -48,8 +48,8 @@ struct odef_ctx {
   // time grid of the last fixed solve
   std::vector<double> tgrid;
   double* d_hs = nullptr;
-  double* d_pvals = nullptr;
-  double* d_tgrid = nullptr;
+  double* d_ptab = nullptr;
+  int* d_tab_idx = nullptr;
   size_t grid_cap = 0;
   long n_save = 0;
   bool adaptive = false;
@@ -275,8 +275,8 @@ void odef_destroy(odef_ctx* c) {
   if (c->d_u0) (void)hipFree(c->d_u0);
   if (c->d_p) (void)hipFree(c->d_p);
   if (c->d_hs) (void)hipFree(c->d_hs);
-  if (c->d_pvals) (void)hipFree(c->d_pvals);
-  if (c->d_tgrid) (void)hipFree(c->d_tgrid);
+  if (c->d_ptab) (void)hipFree(c->d_ptab);
+  if (c->d_tab_idx) (void)hipFree(c->d_tab_idx);
   for (int k = 0; k < 4; ++k)
     if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -414,29 +414,52 @@ int odef_solve_fixed(odef_ctx* c, const double* tgrid, int64_t n_t) {
   c->adaptive = false;
   c->n_save = (c->cfg.save_mode == ODEF_SAVE_EVERYSTEP) ? nsteps + 1 : 1;
   c->tgrid.assign(tgrid, tgrid + n_t);
-  std::vector<double> hs(nsteps), pv(nsteps);
+  // step sizes, and one preconditioner table per distinct h (src/preconditioning.jl:1-17; pval by libm pow
+  // as the reference's h^(-q-1/2))
+  std::vector<double> hs(nsteps), tabs;
+  std::vector<int> idx(nsteps);
+  std::vector<double> distinct;
   for (long n = 0; n < nsteps; ++n) {
     hs[n] = tgrid[n + 1] - tgrid[n];
-    pv[n] = std::pow(hs[n], -c->q - 0.5);  // src/preconditioning.jl:9
+    int k = -1;
+    for (size_t j = distinct.size(); j-- > 0;)
+      if (distinct[j] == hs[n]) { k = (int)j; break; }
+    if (k < 0) {
+      k = (int)distinct.size();
+      distinct.push_back(hs[n]);
+      tabs.resize(distinct.size() * kTabStride, 0.0);
+      double* t = tabs.data() + (size_t)k * kTabStride;
+      const double pval = std::pow(hs[n], -c->q - 0.5);
+      switch (c->q) {
+        case 1: precond_fill<2>(hs[n], pval, t); break;
+        case 2: precond_fill<3>(hs[n], pval, t); break;
+        case 3: precond_fill<4>(hs[n], pval, t); break;
+        case 4: precond_fill<5>(hs[n], pval, t); break;
+        default: precond_fill<6>(hs[n], pval, t); break;
+      }
+    }
+    idx[n] = k;
   }
   if (c->grid_cap < (size_t)n_t) {
-    if (c->d_hs) { HIPCHK(c, hipFree(c->d_hs)); HIPCHK(c, hipFree(c->d_pvals)); HIPCHK(c, hipFree(c->d_tgrid)); }
-    c->d_hs = c->d_pvals = c->d_tgrid = nullptr;
+    if (c->d_hs) { HIPCHK(c, hipFree(c->d_hs)); HIPCHK(c, hipFree(c->d_ptab)); HIPCHK(c, hipFree(c->d_tab_idx)); }
+    c->d_hs = c->d_ptab = nullptr;
+    c->d_tab_idx = nullptr;
+    c->grid_cap = 0;
     HIPCHK(c, hipMalloc((void**)&c->d_hs, sizeof(double) * n_t));
-    HIPCHK(c, hipMalloc((void**)&c->d_pvals, sizeof(double) * n_t));
-    HIPCHK(c, hipMalloc((void**)&c->d_tgrid, sizeof(double) * n_t));
+    HIPCHK(c, hipMalloc((void**)&c->d_ptab, sizeof(double) * n_t * kTabStride));  // worst case: all h distinct
+    HIPCHK(c, hipMalloc((void**)&c->d_tab_idx, sizeof(int) * n_t));
     c->grid_cap = (size_t)n_t;
   }
   HIPCHK(c, hipMemcpyAsync(c->d_hs, hs.data(), sizeof(double) * nsteps, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_pvals, pv.data(), sizeof(double) * nsteps, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_tgrid, tgrid, sizeof(double) * n_t, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // hs/pv are stack-owned host vectors
+  HIPCHK(c, hipMemcpyAsync(c->d_ptab, tabs.data(), sizeof(double) * tabs.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_tab_idx, idx.data(), sizeof(int) * nsteps, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the host vectors are locals
   if (alloc_outputs(c, c->n_save)) return -1;
   FilterParams P;
   fill_params(c, P);
   P.hs = c->d_hs;
-  P.pvals = c->d_pvals;
-  P.tgrid = c->d_tgrid;
+  P.ptab = c->d_ptab;
+  P.tab_idx = c->d_tab_idx;
   P.nsteps = nsteps;
   P.t0 = c->t0;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -492,7 +515,8 @@ int odef_smooth(odef_ctx* c) {
   S.n_save = c->n_save;
   S.adaptive = c->adaptive;
   S.hs = c->d_hs;
-  S.pvals = c->d_pvals;
+  S.ptab = c->d_ptab;
+  S.tab_idx = c->d_tab_idx;
   S.tsave = (const double*)c->f[ODEF_F_T].ptr;
   S.nsaved = (const int*)c->f[ODEF_F_NSAVED].ptr;
   S.mean = (const double*)c->f[ODEF_F_MEAN].ptr;

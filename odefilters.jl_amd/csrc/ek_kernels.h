@@ -12,13 +12,13 @@ constexpr int kWave = 64;
 
 template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kWave) void ek_filter_fixed_kernel(const FilterParams P) {
-  const long i = (long)blockIdx.x * kWave + threadIdx.x;
-  if (i < P.N) filter_fixed_lane<RHS, q, EK1>(P, i);
+  const long i0 = (long)blockIdx.x * kWave;  // wave-uniform
+  if (i0 + threadIdx.x < P.N) filter_fixed_lane<RHS, q, EK1>(P, i0, threadIdx.x);
 }
 template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kWave) void ek_filter_adaptive_kernel(const FilterParams P) {
-  const long i = (long)blockIdx.x * kWave + threadIdx.x;
-  if (i < P.N) filter_adaptive_lane<RHS, q, EK1>(P, i);
+  const long i0 = (long)blockIdx.x * kWave;
+  if (i0 + threadIdx.x < P.N) filter_adaptive_lane<RHS, q, EK1>(P, i0, threadIdx.x);
 }
 template <int d, int q>
 __global__ __launch_bounds__(kWave) void rts_smooth_kernel(const SmoothParams P) {

@@ -19,10 +19,10 @@ struct FilterParams {
   const double* p;   // [np][N] or [np]
   int p_shared;
   long N;
-  // fixed grid (device arrays of length nsteps): h_n and h_n^(-q-1/2)
-  const double* hs;
-  const double* pvals;
-  const double* tgrid;  // [nsteps+1]
+  // fixed grid: preconditioner tables (one per distinct h, see precond_fill) and, per step, which one
+  const double* ptab;    // [n_tables][kTabStride]
+  const int* tab_idx;    // [nsteps]
+  const double* hs;      // [nsteps] step sizes
   long nsteps;
   // adaptive
   double t0, t1, abstol, reltol, dt0;
@@ -44,16 +44,48 @@ struct FilterParams {
   int* retcode;
 };
 
+// Row store: `base` is a wave-uniform pointer to element [field row 0][first trajectory of the
+// wavefront]; consecutive field rows are `N` doubles apart; every lane writes its own column.
+// On the GPU this is a buffer store with the row offset in an SGPR (soffset) and lane*8 in
+// voffset: no per-store VALU address arithmetic, 512 contiguous bytes per wave-instruction.
+#ifdef ODEF_HOST_EMUL
+struct RowStore {
+  double* p;
+  size_t n;
+  RowStore(double* base, size_t N, size_t /*rows*/, unsigned lane) : p(base + lane), n(N) {}
+  void put(double v) { *p = v; p += n; }
+};
+#else
+struct RowStore {
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned voff, soff, step;
+  __device__ RowStore(double* base, size_t N, size_t rows, unsigned lane)
+      : rs(__builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(rows * N * sizeof(double)), 0x00020000)),
+        voff(lane * 8u), soff(0u), step((unsigned)(N * sizeof(double))) {}
+  __device__ void put(double v) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, 0);
+    soff += step;
+    asm volatile("" : "+s"(soff));  // keep the row offset a running scalar (one s_add per store) instead of
+                                    // dozens of hoisted loop-invariant offsets that would spill the SGPR file
+  }
+};
+#endif
+
+// Stores one saved record of one trajectory.  `i0` (first trajectory of the wavefront) and
+// `slot` are wave-uniform, `lane` is the lane index.
 template <int D, int TRI>
-__device__ inline void store_state(const FilterParams& P, long slot, long i, const double (&m)[D],
+__device__ inline void store_state(const FilterParams& P, long slot, long i0, unsigned lane, const double (&m)[D],
                                    const double (&C)[TRI], double diffusion) {
-  double* __restrict__ pm = P.mean + (size_t)slot * D * P.N + i;
+  const size_t N = (size_t)P.N;
+  RowStore sm(P.mean + ((size_t)slot * D * N + i0), N, D, lane);
 #pragma unroll
-  for (int k = 0; k < D; ++k) pm[(size_t)k * P.N] = m[k];
-  double* __restrict__ pcv = P.cov + (size_t)slot * TRI * P.N + i;
+  for (int k = 0; k < D; ++k) sm.put(m[k]);
+  RowStore sc(P.cov + ((size_t)slot * TRI * N + i0), N, TRI, lane);
 #pragma unroll
-  for (int k = 0; k < TRI; ++k) pcv[(size_t)k * P.N] = C[k];
-  P.diff[(size_t)slot * P.N + i] = diffusion;
+  for (int k = 0; k < TRI; ++k) sc.put(C[k]);
+  RowStore sd(P.diff + ((size_t)slot * N + i0), N, 1, lane);
+  sd.put(diffusion);
 }
 
 template <int D>
@@ -65,7 +97,8 @@ __device__ inline bool all_finite(const double (&m)[D]) {
 }
 
 template <class RHS, int q, bool IS_EK1>
-__device__ inline void filter_fixed_lane(const FilterParams& P, long i) {
+__device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigned lane) {
+  const long i = i0 + lane;
   using S = EKStep<RHS, q, IS_EK1>;
   constexpr int d = S::d, D = S::D, TRI = S::TRI, np = RHS::np;
   double pl[np > 0 ? np : 1];
@@ -79,16 +112,16 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i) {
   taylor_init<RHS, q>(u0, pl, m);
 #pragma unroll
   for (int k = 0; k < TRI; ++k) C[k] = 0.0;
-  if (P.everystep) store_state<D, TRI>(P, 0, i, m, C, 0.0);
+  if (P.everystep) store_state<D, TRI>(P, 0, i0, lane, m, C, 0.0);
 
   double loglik = 0.0, gdiff = 0.0;
   int chol_fix = 0;
   for (long n = 0; n < P.nsteps; ++n) {
-    const double h = P.hs[n], pval = P.pvals[n];
+    const double* __restrict__ tab = P.ptab + (size_t)P.tab_idx[n] * kTabStride;  // wave-uniform
     double m2[D], C2[TRI], es[d];
     StepAux aux;
     aux.chol_fix = 0;
-    S::run(P.pc, pl, h, pval, P.fixed_diffusion != 0, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux);
+    S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux);
 #pragma unroll
     for (int k = 0; k < D; ++k) m[k] = m2[k];
 #pragma unroll
@@ -96,9 +129,9 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i) {
     loglik += aux.loglik;
     gdiff = aux.sigma2_global;
     chol_fix += aux.chol_fix;
-    if (P.everystep) store_state<D, TRI>(P, n + 1, i, m, C, gdiff);
+    if (P.everystep) store_state<D, TRI>(P, n + 1, i0, lane, m, C, gdiff);
   }
-  if (!P.everystep) store_state<D, TRI>(P, 0, i, m, C, gdiff);
+  if (!P.everystep) store_state<D, TRI>(P, 0, i0, lane, m, C, gdiff);
   P.loglik[i] = loglik;
   P.naccept[i] = (int)P.nsteps;
   P.nreject[i] = 0;
@@ -121,7 +154,8 @@ __device__ inline double precond_val(double h) {
 // Adaptive filter: perform_step! + error estimate (src/perform_step.jl:78-92) + the PI
 // controller of OrdinaryDiffEq (third-party; exponents src/alg_utils.jl:23-24).
 template <class RHS, int q, bool IS_EK1>
-__device__ inline void filter_adaptive_lane(const FilterParams& P, long i) {
+__device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsigned lane) {
+  const long i = i0 + lane;
   using S = EKStep<RHS, q, IS_EK1>;
   constexpr int d = S::d, D = S::D, TRI = S::TRI, np = RHS::np, NB = q + 1;
   double pl[np > 0 ? np : 1];
@@ -135,7 +169,7 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i) {
   taylor_init<RHS, q>(u0, pl, m);
 #pragma unroll
   for (int k = 0; k < TRI; ++k) C[k] = 0.0;
-  store_state<D, TRI>(P, 0, i, m, C, 0.0);
+  store_state<D, TRI>(P, 0, i0, lane, m, C, 0.0);
   P.tsave[i] = P.t0;
 
   double ucur[d];
@@ -153,11 +187,12 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i) {
     h = fmin(h, ct.dtmax);
     h = fmin(h, P.t1 - t);  // tstop clipping
     if (!(h > ct.dtmin)) { ret = 2; break; }  // DtLessThanMin
-    const double pval = precond_val<q>(h);
+    double tab[kTabStride];
+    precond_fill<NB>(h, precond_val<q>(h), tab);
     double m2[D], C2[TRI], es[d];
     StepAux aux;
     aux.chol_fix = 0;
-    S::run(P.pc, pl, h, pval, P.fixed_diffusion != 0, P.want_loglik != 0, naccept, gdiff, m, C, m2, C2, es, aux);
+    S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, naccept, gdiff, m, C, m2, C2, es, aux);
     // DiffEqBase.calculate_residuals! + ODE_DEFAULT_NORM (src/perform_step.jl:78-84)
     double acc = 0.0;
 #pragma unroll
@@ -179,8 +214,8 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i) {
       qq = fmax(1.0 / ct.qmax, fmin(1.0 / ct.qmin, qq / ct.gamma));
     }
     // cache.x after the attempt when x_filt is not committed: PI*(P*x) (src/perform_step.jl:73)
-    double pj[NB], pij[NB];
-    precond_tables<NB>(h, pval, pj, pij);
+    const double* pj = tab + kTabPJ;
+    const double* pij = tab + kTabPIJ;
     if (EEst <= 1.0) {  // accepted by OrdinaryDiffEq
       if (EEst < 1.0) {  // src/perform_step.jl:89
 #pragma unroll
@@ -199,7 +234,7 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i) {
       t = tn;
       gdiff = aux.sigma2_global;
       ++naccept;
-      store_state<D, TRI>(P, nsaved, i, m, C, gdiff);
+      store_state<D, TRI>(P, nsaved, i0, lane, m, C, gdiff);
       P.tsave[(size_t)nsaved * P.N + i] = t;
       ++nsaved;
       h = h / qq;
@@ -230,8 +265,9 @@ struct SmoothParams {
   long N;
   long n_save;          // fixed: number of saves; adaptive: capacity
   int adaptive;
+  const double* ptab;   // fixed: preconditioner tables
+  const int* tab_idx;   // fixed: [n_save-1]
   const double* hs;     // fixed: [n_save-1]
-  const double* pvals;  // fixed: [n_save-1]
   const double* tsave;  // adaptive: [n_save][N]
   const int* nsaved;    // [N]
   const double* mean;   // filter results
@@ -267,13 +303,19 @@ __device__ inline void smooth_lane(const SmoothParams& P, long i) {
   }
   bool nan_seen = false;
   for (long s = n - 2; s >= 1; --s) {
-    double h, pval;
+    double h;
+    double tabv[kTabStride];
     if (P.adaptive) {
       h = P.tsave[(size_t)(s + 1) * N + i] - P.tsave[(size_t)s * N + i];
-      pval = precond_val<q>(h);
+      if (h != 0.0) precond_fill<NB>(h, precond_val<q>(h), tabv);
     } else {
       h = P.hs[s];
-      pval = P.pvals[s];
+      const double* __restrict__ t = P.ptab + (size_t)P.tab_idx[s] * kTabStride;
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        tabv[kTabPJ + J] = t[kTabPJ + J];
+        tabv[kTabPIJ + J] = t[kTabPIJ + J];
+      }
     }
     if (h == 0.0) {  // src/smoothing.jl:13-16
 #pragma unroll
@@ -283,8 +325,8 @@ __device__ inline void smooth_lane(const SmoothParams& P, long i) {
       continue;
     }
     const double sigma2 = P.diff[(size_t)(s + 1) * N + i];
-    double pj[NB], pij[NB];
-    precond_tables<NB>(h, pval, pj, pij);
+    const double* pj = tabv + kTabPJ;
+    const double* pij = tabv + kTabPIJ;
     double mt[D], Ct[TRI], mst[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {

@@ -119,54 +119,106 @@ __device__ inline void spd_inverse(const double (&S)[n][n], double (&Sinv)[n][n]
   }
 }
 
-// preconditioner (src/preconditioning.jl:1-17): p[J] = h^(J-q-1/2) by the reference's running
-// product starting from `pval = h^(-q-1/2)`; pinv = inv(Diagonal).
+// ---- per-step preconditioner tables -------------------------------------------------------
+// P(h) = diag(h^(j-q-1/2)) (x) I_d (src/preconditioning.jl:1-17), built by the reference's running
+// product from pval = h^(-q-1/2).  Layout of one table (kTabStride doubles):
+//   [0 .. MAXNB)            pj[J]   = P block value
+//   [MAXNB .. 2 MAXNB)      pij[J]  = 1 / pj[J]                      (inv(::Diagonal))
+//   [2 MAXNB + J*MAXNB + K] pp[J][K]   = pj[J]*pj[K]
+//   [2 MAXNB + MAXNB^2 + J*MAXNB + K]  pipi[J][K] = pij[J]*pij[K]
+// Fixed-step solves build one table per distinct h on the host (read through scalar loads:
+// the pointer is wave-uniform); the adaptive kernel fills one per lane in registers.
+constexpr int kTabPJ = 0, kTabPIJ = MAXNB, kTabPP = 2 * MAXNB, kTabPIPI = 2 * MAXNB + MAXNB * MAXNB;
+constexpr int kTabStride = 2 * MAXNB + 2 * MAXNB * MAXNB;
+
 template <int NB>
-__device__ inline void precond_tables(double h, double pval, double (&pj)[NB], double (&pij)[NB]) {
+__host__ __device__ inline void precond_fill(double h, double pval, double* tab) {
   double val = pval;
 #pragma unroll
   for (int J = 0; J < NB; ++J) {
-    pj[J] = val;
-    pij[J] = 1.0 / val;
+    tab[kTabPJ + J] = val;
+    tab[kTabPIJ + J] = 1.0 / val;
     val *= h;
   }
-}
-
-// B = A C A' + sigma2 * Q  on packed symmetric storage, A = At (x) I_d (block upper
-// triangular), i.e. the Gram matrix of `_L = [A*L  sqrt(sigma2)*Q_L]` (src/filtering.jl:34-35).
-// `C` comes in already preconditioned.
-template <int d, int NB>
-__device__ inline void predict_cov_gram(const PriorConsts& pc, const double (&C)[d * NB * (d * NB + 1) / 2],
-                                        double sigma2, double (&B)[d * NB * (d * NB + 1) / 2]) {
-  constexpr int D = d * NB;
-  // T = A * C  (D x D)
-  double T[D][D];
 #pragma unroll
   for (int J = 0; J < NB; ++J)
 #pragma unroll
+    for (int K = 0; K < NB; ++K) {
+      tab[kTabPP + J * MAXNB + K] = tab[kTabPJ + J] * tab[kTabPJ + K];
+      tab[kTabPIPI + J * MAXNB + K] = tab[kTabPIJ + J] * tab[kTabPIJ + K];
+    }
+}
+
+// X <- A X A' + sigma2 * Q  in place on packed symmetric storage, A = At (x) I_d block upper
+// triangular: the Gram matrix of `_L = [A*L  sqrt(sigma2)*Q_L]` (src/filtering.jl:34-35).
+// A = E_{NB-2} ... E_1 E_0 with E_J = I + sum_{j>J} At[J][j] e_J e_j' (block row J picks up the
+// still-untouched block rows j > J), applied as successive symmetric congruences.
+template <int d, int NB>
+__device__ inline void predict_cov_inplace(const PriorConsts& pc, double (&X)[d * NB * (d * NB + 1) / 2], double sigma2) {
+  constexpr int D = d * NB;
+#pragma unroll
+  for (int J = 0; J + 1 < NB; ++J) {
+    // W_JJ = X_JJ + sum_j a_j X_jJ from the old cells (full d x d block, not symmetric)
+    double Wd[d][d];
+#pragma unroll
     for (int a = 0; a < d; ++a)
 #pragma unroll
-      for (int k = 0; k < D; ++k) {
-        double s = C[symidx(J * d + a, k)];
-#pragma unroll
-        for (int j = J + 1; j < NB; ++j) s += pc.At[J][j] * C[symidx(j * d + a, k)];
-        T[J * d + a][k] = s;
-      }
-  // B = T * A' (lower triangle) + sigma2 * Q
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int K = 0; K < NB; ++K)
-#pragma unroll
       for (int b = 0; b < d; ++b) {
-        const int j = K * d + b;
-        if (j > i) continue;
-        double s = T[i][j];
+        double t = X[symidx(J * d + a, J * d + b)];
 #pragma unroll
-        for (int k = K + 1; k < NB; ++k) s += T[i][k * d + b] * pc.At[K][k];
-        if ((i % d) == b) s += sigma2 * pc.Qt[i / d][K];
-        B[tri(i, j)] = s;
+        for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * X[symidx(j * d + a, J * d + b)];
+        Wd[a][b] = t;
       }
+    // off-diagonal blocks of block row J: X_Jk += sum_j a_j X_jk  (k != J)
+#pragma unroll
+    for (int a = 0; a < d; ++a)
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        if (c / d == J) continue;
+        double t = X[symidx(J * d + a, c)];
+#pragma unroll
+        for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * X[symidx(j * d + a, c)];
+        X[symidx(J * d + a, c)] = t;
+      }
+    // Y_JJ = W_JJ + sum_j a_j W_Jj
+#pragma unroll
+    for (int a = 0; a < d; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) {
+        double t = Wd[a][b];
+#pragma unroll
+        for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * X[symidx(J * d + a, j * d + b)];
+        X[tri(J * d + a, J * d + b)] = t;
+      }
+  }
+#pragma unroll
+  for (int J = 0; J < NB; ++J)
+#pragma unroll
+    for (int K = 0; K <= J; ++K)
+#pragma unroll
+      for (int a = 0; a < d; ++a) X[tri(J * d + a, K * d + a)] += sigma2 * pc.Qt[J][K];
+}
+
+// Cholesky of a small SPD matrix, lower factor L and the reciprocals of its diagonal.
+template <int n>
+__device__ inline void chol_small(const double (&S)[n][n], double (&L)[n][n], double (&Ldinv)[n]) {
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    double s = S[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+    const double ljj = sqrt(s);
+    L[j][j] = ljj;
+    const double inv = 1.0 / ljj;
+    Ldinv[j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < n; ++i) {
+      double t = S[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+      L[i][j] = t * inv;
+    }
+  }
 }
 
 template <class RHS, int q, bool IS_EK1>
@@ -175,26 +227,33 @@ struct EKStep {
   static constexpr int NB = q + 1;
   static constexpr int D = d * NB;
   static constexpr int TRI = D * (D + 1) / 2;
+  static constexpr int d2 = 2 * d;
 
   // One attempted step (src/perform_step.jl:27-76).  Inputs m, C: current filter state
-  // (un-preconditioned, as `cache.x`).  Outputs m_out, C_out: `cache.x_filt` (un-preconditioned).
+  // (un-preconditioned, as `cache.x`; C = packed Sigma).  Outputs m_out, C_out: `cache.x_filt`.
   // err_scale[r] = sqrt(diag(H (sigma2_local Q) H'))  (src/perform_step.jl:148-158).
-  __device__ static inline void run(const PriorConsts& pc, const double* __restrict__ p, double h, double pval,
+  // `tab`: preconditioner table of this step's h (see precond_fill).
+  //
+  // Square-root structure inside the step: the predicted covariance is Cholesky-factorised
+  // (src/filtering.jl:36) -- only its first 2d columns are needed because H = (E1 - J E0) P^-1
+  // has support on the first two derivative blocks -- S = (H L)(H L)' is formed from the factor
+  // (src/perform_step.jl:54), and the Joseph update (I - K H) L (src/filtering.jl:89) is carried
+  // out as the orthogonal transformation that triangularises (H L)': with (H L1)' = Q [R; 0],
+  //   K = (L1 Q)[:, :d] R^-T,   Sigma_filt = (L1 Q)[:, d:2d] (L1 Q)[:, d:2d]' + Schur complement,
+  // which is the Gram matrix of (I - K H) L without ever forming K H.
+  __device__ static inline void run(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab,
                                     bool fixed_diffusion, bool want_loglik, int success_iter, double prev_global,
                                     const double (&m)[D], const double (&C)[TRI], double (&m_out)[D],
                                     double (&C_out)[TRI], double (&err_scale)[d], StepAux& aux) {
-    double pj[NB], pij[NB];
-    precond_tables<NB>(h, pval, pj, pij);
-
     // x~ = P x  (src/perform_step.jl:36-38)
     double mt[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) mt[i] = pj[i / d] * m[i];
-    double Ct[TRI];
+    for (int i = 0; i < D; ++i) mt[i] = tab[kTabPJ + i / d] * m[i];
+    double X[TRI];
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
-      for (int j = 0; j <= i; ++j) Ct[tri(i, j)] = (C[tri(i, j)] * pj[i / d]) * pj[j / d];
+      for (int j = 0; j <= i; ++j) X[tri(i, j)] = C[tri(i, j)] * tab[kTabPP + (i / d) * MAXNB + (j / d)];
 
     // predict mean (src/filtering.jl:22-25)
     double mp[D];
@@ -209,12 +268,13 @@ struct EKStep {
       }
 
     // measure! (src/perform_step.jl:95-132)
+    const double pi0 = tab[kTabPIJ + 0], pi1 = tab[kTabPIJ + 1];
     double up[d], du[d], z[d];
 #pragma unroll
-    for (int a = 0; a < d; ++a) up[a] = pij[0] * mp[a];
+    for (int a = 0; a < d; ++a) up[a] = pi0 * mp[a];
     RHS::f(up, p, du);
 #pragma unroll
-    for (int a = 0; a < d; ++a) z[a] = pij[1] * mp[d + a] - du[a];
+    for (int a = 0; a < d; ++a) z[a] = pi1 * mp[d + a] - du[a];
     // H = (E1 - J E0) PI  -> blocks H0 = -J*pi0, H1 = I*pi1 ; EK0: H0 = 0
     double H0[d][d];
     if constexpr (IS_EK1) {
@@ -223,14 +283,14 @@ struct EKStep {
 #pragma unroll
       for (int r = 0; r < d; ++r)
 #pragma unroll
-        for (int a = 0; a < d; ++a) H0[r][a] = (0.0 - Jm[r][a]) * pij[0];
+        for (int a = 0; a < d; ++a) H0[r][a] = (0.0 - Jm[r][a]) * pi0;
     } else {
 #pragma unroll
       for (int r = 0; r < d; ++r)
 #pragma unroll
         for (int a = 0; a < d; ++a) H0[r][a] = 0.0;
     }
-    const double h1 = pij[1];  // H1 = h1 * I
+    const double h1 = pi1;  // H1 = h1 * I
 
     // M = H Q_L (d x 2d nonzero), W = M M' = H Q H'   (src/diffusions.jl:78)
     double W[d][d];
@@ -240,7 +300,11 @@ struct EKStep {
 #pragma unroll
       for (int r = 0; r < d; ++r)
 #pragma unroll
-        for (int a = 0; a < d; ++a) M0[r][a] = H0[r][a] * pc.QLt[0][0] + (r == a ? h1 * pc.QLt[1][0] : 0.0);
+        for (int a = 0; a < d; ++a) {
+          double t = (r == a) ? h1 * pc.QLt[1][0] : 0.0;
+          if constexpr (IS_EK1) t += H0[r][a] * pc.QLt[0][0];
+          M0[r][a] = t;
+        }
 #pragma unroll
       for (int r = 0; r < d; ++r)
 #pragma unroll
@@ -255,64 +319,107 @@ struct EKStep {
 
     double sigma2_pred = 1.0;  // diffusion used inside predict_cov!
     if (!fixed_diffusion) {
-      // DynamicDiffusion (src/diffusions.jl:72-80): sigma^2 = z' (H Q H')^-1 z / d
-      double Winv[d][d];
-      spd_inverse<d>(W, Winv, nullptr);
-      double s = 0.0;
+      // DynamicDiffusion (src/diffusions.jl:72-80): sigma^2 = z' (H Q H')^-1 z / d = |Lw^-1 z|^2 / d
+      double Lw[d][d], Lwi[d];
+      chol_small<d>(W, Lw, Lwi);
+      double s = 0.0, yw[d];
 #pragma unroll
       for (int r = 0; r < d; ++r) {
-        double t = 0.0;
+        double t = z[r];
 #pragma unroll
-        for (int c = 0; c < d; ++c) t += Winv[r][c] * z[c];
-        s += z[r] * t;
+        for (int c = 0; c < r; ++c) t -= Lw[r][c] * yw[c];
+        yw[r] = t * Lwi[r];
+        s += yw[r] * yw[r];
       }
       sigma2_pred = s / d;
       aux.sigma2_local = sigma2_pred;
       aux.sigma2_global = sigma2_pred;
     }
 
-    // predict_cov! (src/filtering.jl:33-48): Gram + Cholesky
-    double Lp[TRI];
-    predict_cov_gram<d, NB>(pc, Ct, sigma2_pred, Lp);
-    chol_packed<D>(Lp, aux.chol_fix);
+    // predict_cov! (src/filtering.jl:33-41): Gram matrix, then Cholesky -- first 2d columns,
+    // right-looking, so that X[i>=2d][j>=2d] ends as the Schur complement L2 L2'.
+    predict_cov_inplace<d, NB>(pc, X, sigma2_pred);
+#pragma unroll
+    for (int k = 0; k < d2; ++k) {
+      const double piv = X[tri(k, k)];
+      const bool ok = piv > 0.0;  // a failing pivot is the reference's QR-fallback case (src/filtering.jl:38-47)
+      const double lkk = ok ? sqrt(piv) : 0.0;
+      const double inv = ok ? 1.0 / lkk : 0.0;
+      aux.chol_fix += ok ? 0 : 1;
+      X[tri(k, k)] = lkk;
+#pragma unroll
+      for (int i = k + 1; i < D; ++i) X[tri(i, k)] *= inv;
+#pragma unroll
+      for (int j = k + 1; j < D; ++j) {
+        const double ljk = X[tri(j, k)];
+#pragma unroll
+        for (int i = j; i < D; ++i) X[tri(i, j)] -= X[tri(i, k)] * ljk;
+      }
+    }
 
-    // HL = H L^-  (d x 2d nonzero), S = HL HL'  (src/perform_step.jl:54,129)
-    double HL[d][2 * d];
+    // G = (H L1)' (2d x d):  G[c][r] = sum_{k>=c} H[r][k] L[k][c]
+    double G[d2][d];
 #pragma unroll
-    for (int r = 0; r < d; ++r)
+    for (int c = 0; c < d2; ++c)
 #pragma unroll
-      for (int c = 0; c < 2 * d; ++c) {
+      for (int r = 0; r < d; ++r) {
         double s = 0.0;
+        if constexpr (IS_EK1) {
 #pragma unroll
-        for (int k = c; k < 2 * d; ++k) {
-          if (k < d) s += H0[r][k] * Lp[tri(k, c)];
-          else if (k - d == r) s += h1 * Lp[tri(k, c)];
+          for (int k = c; k < d; ++k) s += H0[r][k] * X[tri(k, c)];
         }
-        HL[r][c] = s;
+        if (d + r >= c) s += h1 * X[tri(d + r, c)];
+        G[c][r] = s;
       }
-    double S[d][d], Sinv[d][d];
+    // Householder QR of G: G = Q [R; 0];  S = G'G = R'R  (measurement covariance, src/perform_step.jl:54)
+    double hv[d][d2], hbeta[d], R[d][d];
 #pragma unroll
-    for (int r = 0; r < d; ++r)
+    for (int k = 0; k < d; ++k) {
+      double nrm2 = 0.0;
 #pragma unroll
-      for (int s = 0; s <= r; ++s) {
-        double t = 0.0;
+      for (int i = k; i < d2; ++i) nrm2 += G[i][k] * G[i][k];
+      const double nrm = sqrt(nrm2);
+      const double x0 = G[k][k];
+      const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+      const double v0 = x0 - alpha;
+      const double vtv = nrm2 - x0 * x0 + v0 * v0;
+      const double beta = (vtv > 0.0) ? 2.0 / vtv : 0.0;
+      hbeta[k] = beta;
+      hv[k][k] = v0;
 #pragma unroll
-        for (int c = 0; c < 2 * d; ++c) t += HL[r][c] * HL[s][c];
-        S[r][s] = t;
-        S[s][r] = t;
+      for (int i = k + 1; i < d2; ++i) hv[k][i] = G[i][k];
+      R[k][k] = alpha;
+#pragma unroll
+      for (int c = k + 1; c < d; ++c) {
+        double s = v0 * G[k][c];
+#pragma unroll
+        for (int i = k + 1; i < d2; ++i) s += hv[k][i] * G[i][c];
+        s *= beta;
+        G[k][c] -= s * v0;
+#pragma unroll
+        for (int i = k + 1; i < d2; ++i) G[i][c] -= s * hv[k][i];
+        R[k][c] = G[k][c];
       }
-    double logdetS = 0.0;
-    spd_inverse<d>(S, Sinv, want_loglik ? &logdetS : nullptr);
-    double zSz = 0.0;
+    }
+    // y = R^-T z ;  z' S^-1 z = y'y ;  log det S = 2 sum log |R_kk|
+    double y[d], zSz = 0.0, detprod = 1.0, logacc = 0.0;
 #pragma unroll
     for (int r = 0; r < d; ++r) {
-      double t = 0.0;
+      double t = z[r];
 #pragma unroll
-      for (int c = 0; c < d; ++c) t += Sinv[r][c] * z[c];
-      zSz += z[r] * t;
+      for (int c = 0; c < r; ++c) t -= R[c][r] * y[c];
+      y[r] = t / R[r][r];
+      zSz += y[r] * y[r];
+      if constexpr (d <= 4) detprod *= R[r][r];
+      else if (want_loglik) logacc += log(fabs(R[r][r]));
     }
-    // logpdf(measurement, 0) (src/perform_step.jl:66)
-    aux.loglik = want_loglik ? -0.5 * (zSz + logdetS + d * 1.8378770664093453) : 0.0;
+    if (want_loglik) {
+      if constexpr (d <= 4) logacc = log(fabs(detprod));
+      // logpdf(measurement, 0) (src/perform_step.jl:66)
+      aux.loglik = -0.5 * (zSz + 2.0 * logacc + d * 1.8378770664093453);
+    } else {
+      aux.loglik = 0.0;
+    }
 
     if (fixed_diffusion) {
       // FixedDiffusion (src/diffusions.jl:11-36): running mean of z' S^-1 z / d
@@ -325,60 +432,40 @@ struct EKStep {
 #pragma unroll
     for (int r = 0; r < d; ++r) err_scale[r] = sqrt(aux.sigma2_local * W[r][r]);
 
-    // update! (src/filtering.jl:79-91):  K = P_p H' S^-1 = L^- (HL)' S^-1
-    double K[D][d];
+    // update! (src/filtering.jl:79-91): rows of L1 times Q
+    double Zp[D][d];
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-      double w[d];
+    for (int l = 0; l < D; ++l) {
+      double w[d2];
 #pragma unroll
-      for (int r = 0; r < d; ++r) {
+      for (int c = 0; c < d2; ++c) w[c] = (c <= l) ? X[tri(l, c)] : 0.0;
+#pragma unroll
+      for (int k = 0; k < d; ++k) {
         double s = 0.0;
 #pragma unroll
-        for (int c = 0; c < 2 * d; ++c)
-          if (c <= i) s += Lp[tri(i, c)] * HL[r][c];
-        w[r] = s;
-      }
+        for (int c = k; c < d2; ++c) s += w[c] * hv[k][c];
+        s *= hbeta[k];
 #pragma unroll
-      for (int r = 0; r < d; ++r) {
-        double s = 0.0;
-#pragma unroll
-        for (int c = 0; c < d; ++c) s += w[c] * Sinv[c][r];
-        K[i][r] = s;
+        for (int c = k; c < d2; ++c) w[c] -= s * hv[k][c];
       }
+      // m = m_p + K (0 - z),  K z = (L1 Q)[:, :d] y
+      double t = mp[l];
+#pragma unroll
+      for (int r = 0; r < d; ++r) t -= w[r] * y[r];
+      m_out[l] = tab[kTabPIJ + l / d] * t;  // un-precondition (src/perform_step.jl:75)
+#pragma unroll
+      for (int r = 0; r < d; ++r) Zp[l][r] = w[d + r];
     }
-    // m = m_p + K (0 - z);  L = (I - K H) L^-  (only the first 2d columns change)
-    double mf[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-      double s = mp[i];
-#pragma unroll
-      for (int r = 0; r < d; ++r) s += K[i][r] * (0.0 - z[r]);
-      mf[i] = s;
-    }
-    double Lf[D][2 * d];
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-      for (int c = 0; c < 2 * d; ++c) {
-        double s = (c <= i) ? Lp[tri(i, c)] : 0.0;
-#pragma unroll
-        for (int r = 0; r < d; ++r) s -= K[i][r] * HL[r][c];
-        Lf[i][c] = s;
-      }
-    // Sigma_filt = L L' (src/squarerootmatrix.jl:16), then un-precondition (src/perform_step.jl:73-75)
+    // Sigma_filt = Zp Zp' + Schur, then un-precondition (src/perform_step.jl:73-75)
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
       for (int j = 0; j <= i; ++j) {
-        double s = 0.0;
+        double s = (j >= d2) ? X[tri(i, j)] : 0.0;
 #pragma unroll
-        for (int c = 0; c < 2 * d; ++c) s += Lf[i][c] * Lf[j][c];
-#pragma unroll
-        for (int c = 2 * d; c <= j; ++c) s += Lp[tri(i, c)] * Lp[tri(j, c)];
-        C_out[tri(i, j)] = (s * pij[i / d]) * pij[j / d];
+        for (int r = 0; r < d; ++r) s += Zp[i][r] * Zp[j][r];
+        C_out[tri(i, j)] = s * tab[kTabPIPI + (i / d) * MAXNB + (j / d)];
       }
-#pragma unroll
-    for (int i = 0; i < D; ++i) m_out[i] = pij[i / d] * mf[i];
   }
 };
 

@@ -43,7 +43,7 @@ class EmulArgs(C.Structure):
         ("rhs", C.c_int), ("q", C.c_int), ("ek1", C.c_int), ("adaptive", C.c_int),
         ("N", C.c_long), ("u0", dp), ("p", dp), ("p_shared", C.c_int),
         ("At", dp), ("Qt", dp), ("QLt", dp),
-        ("hs", dp), ("pvals", dp), ("tgrid", dp), ("nsteps", C.c_long),
+        ("hs", dp), ("ptab", dp), ("tab_idx", ip), ("nsteps", C.c_long),
         ("t0", C.c_double), ("t1", C.c_double), ("abstol", C.c_double), ("reltol", C.c_double), ("dt0", C.c_double),
         ("ctrl", dp), ("max_save", C.c_long),
         ("everystep", C.c_int), ("fixed_diffusion", C.c_int), ("want_loglik", C.c_int),
@@ -104,15 +104,22 @@ def emul_solve(rhs_id, d, q, ek1, u0s, p, *, tgrid=None, adaptive=False, t0=0.0,
     a.At, a.Qt, a.QLt = _p(At), _p(Qt), _p(QLt)
     if adaptive:
         n_save = max_save
-        hs = pv = tg = np.zeros(1)
+        hs = ptab = tg = np.zeros(1)
+        tab_idx = np.zeros(1, np.int32)
         nsteps = 0
     else:
         tg = np.ascontiguousarray(np.asarray(tgrid, float))
         hs = np.ascontiguousarray(np.diff(tg))
-        pv = np.array([h ** (-q - 1 / 2) for h in hs])
         nsteps = len(hs)
         n_save = nsteps + 1 if everystep else 1
-    a.hs, a.pvals, a.tgrid, a.nsteps = _p(hs), _p(pv), _p(tg), nsteps
+        uniq, inv = np.unique(hs, return_inverse=True)
+        stride = lib().emul_tab_stride()
+        ptab = np.zeros((len(uniq), stride))
+        lib().emul_precond_fill.argtypes = [C.c_int, C.c_double, C.c_double, dp]
+        for k, h in enumerate(uniq):
+            lib().emul_precond_fill(q, float(h), float(h) ** (-q - 1 / 2), _p(ptab[k]))
+        tab_idx = np.ascontiguousarray(inv.astype(np.int32))
+    a.hs, a.ptab, a.tab_idx, a.nsteps = _p(hs), _p(ptab), _p(tab_idx, ip), nsteps
     a.t0, a.t1, a.abstol, a.reltol, a.dt0 = t0, t1, abstol, reltol, dt0
     a.ctrl, a.max_save = _p(ctrl), max_save
     a.everystep, a.fixed_diffusion, a.want_loglik = int(everystep), int(fixed_diffusion), int(want_loglik)

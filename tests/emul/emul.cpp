@@ -14,7 +14,8 @@ struct EmulArgs {
   const double *u0, *p;
   int p_shared;
   const double *At, *Qt, *QLt;  // MAXNB*MAXNB each
-  const double *hs, *pvals, *tgrid;
+  const double *hs, *ptab;
+  const int* tab_idx;
   long nsteps;
   double t0, t1, abstol, reltol, dt0;
   const double* ctrl;  // 10
@@ -32,7 +33,7 @@ static void fill(const EmulArgs& a, FilterParams& P) {
   std::memcpy(P.pc.Qt, a.Qt, sizeof(P.pc.Qt));
   std::memcpy(P.pc.QLt, a.QLt, sizeof(P.pc.QLt));
   P.u0 = a.u0; P.p = a.p; P.p_shared = a.p_shared; P.N = a.N;
-  P.hs = a.hs; P.pvals = a.pvals; P.tgrid = a.tgrid; P.nsteps = a.nsteps;
+  P.hs = a.hs; P.ptab = a.ptab; P.tab_idx = a.tab_idx; P.nsteps = a.nsteps;
   P.t0 = a.t0; P.t1 = a.t1; P.abstol = a.abstol; P.reltol = a.reltol; P.dt0 = a.dt0;
   std::memcpy(&P.ctrl, a.ctrl, sizeof(Controller));
   P.max_save = a.max_save;
@@ -48,8 +49,9 @@ struct RunFilter {
   template <class RHS, int q, bool EK1>
   void operator()() {
     for (long i = 0; i < P.N; ++i) {
-      if (adaptive) filter_adaptive_lane<RHS, q, EK1>(P, i);
-      else filter_fixed_lane<RHS, q, EK1>(P, i);
+      const long i0 = (i / 64) * 64;
+      if (adaptive) filter_adaptive_lane<RHS, q, EK1>(P, i0, (unsigned)(i - i0));
+      else filter_fixed_lane<RHS, q, EK1>(P, i0, (unsigned)(i - i0));
     }
   }
 };
@@ -81,7 +83,7 @@ extern "C" int emul_smooth(const EmulArgs* a, int d) {
   std::memcpy(P.pc.Qt, a->Qt, sizeof(P.pc.Qt));
   std::memcpy(P.pc.QLt, a->QLt, sizeof(P.pc.QLt));
   P.N = a->N; P.n_save = a->n_save; P.adaptive = a->adaptive;
-  P.hs = a->hs; P.pvals = a->pvals; P.tsave = a->tsave; P.nsaved = a->nsaved;
+  P.hs = a->hs; P.ptab = a->ptab; P.tab_idx = a->tab_idx; P.tsave = a->tsave; P.nsaved = a->nsaved;
   P.mean = a->mean; P.cov = a->cov; P.diff = a->diff; P.smean = a->smean; P.scov = a->scov;
   P.retcode = a->retcode;
   RunSmooth r{P};
@@ -89,3 +91,15 @@ extern "C" int emul_smooth(const EmulArgs* a, int d) {
   if (d == 3) return dispatch_smooth_order<3>(a->q, r);
   return -2;
 }
+
+// precond_fill of ek_math.h for the Python driver (same source as the product's host tables)
+extern "C" void emul_precond_fill(int q, double h, double pval, double* tab) {
+  switch (q) {
+    case 1: precond_fill<2>(h, pval, tab); break;
+    case 2: precond_fill<3>(h, pval, tab); break;
+    case 3: precond_fill<4>(h, pval, tab); break;
+    case 4: precond_fill<5>(h, pval, tab); break;
+    case 5: precond_fill<6>(h, pval, tab); break;
+  }
+}
+extern "C" int emul_tab_stride() { return kTabStride; }

@@ -38,7 +38,7 @@ def test_golden_fixed_step(pkg, name):
     for i in range(len(u0s)):
         for smoothed, (m, c, gm, gc) in ((False, (mf, cf, g["mean_filt"], g["cov_filt"])),
                                          (True, (ms, cs, g["mean_smooth"], g["cov_smooth"]))):
-            _, nm, nc = P.oracle_noise(vf, alg_o, u0s[i], kw, smoothed, n_pert=2)
+            _, nm, nc = P.oracle_noise(vf, alg_o, u0s[i], kw, smoothed)
             P.check_against_oracle(m[i], c[i], gm[i], gc[i], vf.d, nm, nc, f"{name}[{i}] smoothed={smoothed}")
     np.testing.assert_allclose(sol.diffusions, g["diffusions"], rtol=1e-6)
     if diffusion == "dynamic":
@@ -94,7 +94,7 @@ def test_ensemble_parity_with_oracle(pkg, rhs, kind, q, dt, t1):
     mf, cf, ms, cs = sol.x_filt_mean(), sol.x_filt_cov(), sol.x_smooth_mean(), sol.x_smooth_cov()
     for i in (0, 63, 64, 129):
         for smoothed, (m, c) in ((False, (mf, cf)), (True, (ms, cs))):
-            base, nm, nc = P.oracle_noise(vf, alg_o, u0s[i], dict(tspan=(0.0, t1), dt=dt), smoothed, n_pert=2)
+            base, nm, nc = P.oracle_noise(vf, alg_o, u0s[i], dict(tspan=(0.0, t1), dt=dt), smoothed)
             P.check_against_oracle(m[i], c[i], base.means(smoothed=smoothed), base.covs(smoothed=smoothed), vf.d, nm, nc,
                                    f"{rhs} {kind}({q}) traj {i} smoothed={smoothed}")
 
