@@ -35,12 +35,16 @@ def cpu_baseline(seconds_budget=15.0):
     its C twin, timed on this box's host cores on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     try:
-        import odefilter_cport as cport  # C restatement, OpenMP over trajectories
+        import subprocess
+
+        # rebuild for THIS host's cores (-march=native); the checker's build, not the product's
+        subprocess.run(["make", "-B", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        import odefilter_cport as cport  # C restatement of the reference loop, OpenMP over trajectories
 
         if cport.available():
             return cport.bench_lorenz(seconds_budget)
-    except Exception:
-        pass
+    except Exception as e:  # fall back to the numpy oracle (slower, 1 thread)
+        print(f"[bench] C restatement unavailable ({e}); timing the numpy oracle instead", file=sys.stderr)
     import odefilter_oracle as orc
 
     vf = orc.vector_field("lorenz63")

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -370,6 +371,10 @@ static void fill_params(odef_ctx* c, FilterParams& P) {
   P.everystep = c->cfg.save_mode == ODEF_SAVE_EVERYSTEP;
   P.fixed_diffusion = c->cfg.diffusion == ODEF_DIFFUSION_FIXED;
   P.want_loglik = c->cfg.want_loglik;
+  {
+    const char* e = getenv("ODEF_STAGGER");
+    P.stagger = e ? atoi(e) : 0;
+  }
   P.mean = (double*)c->f[ODEF_F_MEAN].ptr;
   P.cov = (double*)c->f[ODEF_F_COV_TRIL].ptr;
   P.diff = (double*)c->f[ODEF_F_DIFFUSION].ptr;

@@ -13,6 +13,13 @@ constexpr int kWave = 64;
 template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kWave) void ek_filter_fixed_kernel(const FilterParams P) {
   const long i0 = (long)blockIdx.x * kWave;  // wave-uniform
+  // All waves run the same instruction stream and would reach their per-step store burst
+  // (91 x 512 B at D = 12) together; a one-off start skew spreads the bursts over the step period
+  // so that the HBM write stream is steady.  Speed only: results do not depend on it.
+  if (P.stagger > 0) {
+    const int n = (int)(blockIdx.x % 16u) * P.stagger;
+    for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
+  }
   if (i0 + threadIdx.x < P.N) filter_fixed_lane<RHS, q, EK1>(P, i0, threadIdx.x);
 }
 template <class RHS, int q, bool EK1>

@@ -30,6 +30,7 @@ struct FilterParams {
   long max_save;  // capacity of the save axis (adaptive)
   // options
   int everystep, fixed_diffusion, want_loglik;
+  int stagger;  // start skew between wavefronts in units of s_sleep (64 clocks); 0 = off
   // outputs
   double* mean;    // [n_save][D][N]
   double* cov;     // [n_save][TRI][N]
