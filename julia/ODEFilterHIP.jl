@@ -1,0 +1,97 @@
+# ODEFilterHIP.jl -- the `ccall` binding a ProbNumDiffEq maintainer would add so that
+#
+#     solve(EnsembleProblem(prob; ...), EK1(order=3), EnsembleHIP(); trajectories=N, dt=..., adaptive=false)
+#
+# runs the Kalman predict/update/smooth hot path on an MI355X through libodefilter_hip.so
+# (C ABI: include/odefilter.h).  NOT EXECUTED in the build image (no Julia toolchain there);
+# it mirrors, call for call, what odefilters.jl_amd/host.py does over ctypes, which IS tested.
+module ODEFilterHIP
+
+using ProbNumDiffEq            # EK0, EK1 (src/algorithms.jl:23-51)
+import DiffEqBase
+
+const LIB = get(ENV, "ODEFILTER_HIP_LIB", "libodefilter_hip.so")
+
+# ---- mirrors of the C structs -------------------------------------------------------------
+struct OdefConfig                      # odef_config, 56 bytes
+    struct_size::Int32; alg::Int32; order::Int32; diffusion::Int32; smooth::Int32
+    rhs_id::Int32; d::Int32; n_params::Int32; params_shared::Int32; save_mode::Int32
+    device::Int32; want_loglik::Int32; n_traj::Int64
+end
+
+const RHS_IDS = Dict(:fhn => 0, :lorenz63 => 1, :lotka_volterra => 2, :vanderpol => 3, :linear => 4)
+const DIFFUSIONS = Dict(:dynamic => 0, :fixed => 1)
+const F_MEAN, F_COV_TRIL, F_DIFFUSION, F_T, F_LOGLIK, F_NACCEPT, F_NREJECT, F_NF, F_NJAC, F_NSAVED,
+      F_RETCODE, F_SMOOTH_MEAN, F_SMOOTH_COV_TRIL = 0:12
+const RETCODES = (:Success, :MaxIters, :DtLessThanMin, :Unstable, :Unstable)
+
+"""Ensemble algorithm: all trajectories of an `EnsembleProblem` on one GPU, one lane per trajectory."""
+struct EnsembleHIP <: DiffEqBase.EnsembleAlgorithm
+    device::Int
+    rhs::Symbol          # which compiled-in vector field `prob.f` corresponds to
+end
+EnsembleHIP(rhs::Symbol; device=-1) = EnsembleHIP(device, rhs)
+
+lasterr(ctx) = unsafe_string(ccall((:odef_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx))
+check(rc, ctx) = rc == 0 || error("libodefilter_hip: " * lasterr(ctx))
+
+function fetch(ctx, field, ::Type{T}, dims...) where {T}
+    out = Array{T}(undef, dims...)
+    GC.@preserve out check(ccall((:odef_get, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Csize_t),
+                                 ctx, field, out, sizeof(out)), ctx)
+    out
+end
+
+"""
+    __solve(ensembleprob, alg::Union{EK0,EK1}, ::EnsembleHIP; trajectories, dt, adaptive, abstol, reltol)
+
+`u0s` is a d x N matrix (column = trajectory) -- exactly the memory layout `odef_set_problem` expects.
+Returns the per-trajectory solution fields as arrays with the trajectory index FIRST (Julia column-major
+view of the device layout [n_save][D][N]): `mean[i, k, s]`.
+"""
+function DiffEqBase.__solve(eprob::DiffEqBase.EnsembleProblem, alg::Union{EK0,EK1}, ealg::EnsembleHIP;
+                            trajectories::Int, u0s::Matrix{Float64}, dt=nothing, adaptive=true,
+                            abstol=1e-6, reltol=1e-3, max_steps=4096, kwargs...)
+    prob = eprob.prob
+    d, N = size(u0s); @assert N == trajectories
+    q = alg.order; D = d * (q + 1); TRI = D * (D + 1) ÷ 2
+    p = collect(Float64, prob.p)
+    !adaptive && dt === nothing && error("Fixed timestep methods require a choice of dt or choosing the tstops")
+    cfg = Ref(OdefConfig(sizeof(OdefConfig), alg isa EK1 ? 1 : 0, q, DIFFUSIONS[alg.diffusionmodel],
+                         alg.smooth ? 1 : 0, RHS_IDS[ealg.rhs], d, length(p), 1, 1, ealg.device, 1, N))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:odef_create, LIB), Cint, (Ptr{Ptr{Cvoid}}, Ptr{OdefConfig}), h, cfg)
+    rc == 0 || error("libodefilter_hip: " * lasterr(C_NULL))
+    ctx = h[]
+    try
+        t0, t1 = Float64.(prob.tspan)
+        GC.@preserve u0s p check(ccall((:odef_set_problem, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble),
+                                       ctx, u0s, p, t0), ctx)
+        if adaptive
+            check(ccall((:odef_solve_adaptive, LIB), Cint,
+                        (Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cvoid}, Int64),
+                        ctx, t1, abstol, reltol, dt === nothing ? 1e-3 * (t1 - t0) : dt, C_NULL, max_steps), ctx)
+        else
+            tgrid = collect(t0:dt:t1); tgrid[end] < t1 && push!(tgrid, t1)   # OrdinaryDiffEq's clipped last step
+            GC.@preserve tgrid check(ccall((:odef_solve_fixed, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64),
+                                           ctx, tgrid, length(tgrid)), ctx)
+        end
+        alg.smooth && check(ccall((:odef_smooth, LIB), Cint, (Ptr{Cvoid},), ctx), ctx)
+        ns = Int(ccall((:odef_n_save, LIB), Int64, (Ptr{Cvoid},), ctx))
+        mean = fetch(ctx, alg.smooth ? F_SMOOTH_MEAN : F_MEAN, Float64, N, D, ns)
+        cov  = fetch(ctx, alg.smooth ? F_SMOOTH_COV_TRIL : F_COV_TRIL, Float64, N, TRI, ns)
+        return (t = adaptive ? fetch(ctx, F_T, Float64, N, ns) : fetch(ctx, F_T, Float64, ns),
+                u = view(mean, :, 1:d, :), x_mean = mean, x_cov_tril = cov,
+                x_filt_mean = fetch(ctx, F_MEAN, Float64, N, D, ns),
+                diffusions = fetch(ctx, F_DIFFUSION, Float64, N, ns)[:, 2:end],
+                log_likelihood = fetch(ctx, F_LOGLIK, Float64, N),
+                destats = (nf = fetch(ctx, F_NF, Int32, N), njacs = fetch(ctx, F_NJAC, Int32, N),
+                           naccept = fetch(ctx, F_NACCEPT, Int32, N), nreject = fetch(ctx, F_NREJECT, Int32, N)),
+                nsaved = fetch(ctx, F_NSAVED, Int32, N),
+                retcode = [RETCODES[r + 1] for r in fetch(ctx, F_RETCODE, Int32, N)])
+    finally
+        ccall((:odef_destroy, LIB), Cvoid, (Ptr{Cvoid},), ctx)
+    end
+end
+
+end # module

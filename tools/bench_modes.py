@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the headline): RTS smoother, adaptive filter, final-only save.
+Prints one JSON line per mode; kernel times come from hipEvents inside the library."""
+import argparse, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import odefilters_jl_amd as pkg
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--traj", type=int, default=16384)
+ap.add_argument("--nsteps", type=int, default=1024)
+ap.add_argument("--modes", default="smooth,adaptive")
+args = ap.parse_args()
+N, ns, dt = args.traj, args.nsteps, 2.0**-9
+D, TRI = 12, 78
+for mode in args.modes.split(","):
+    if mode == "smooth":
+        ctx = pkg.Context("lorenz63", 3, 1, N, smooth=True)
+        ctx.set_problem_perturbed([1.0, 0.0, 0.0], [10.0, 28.0, 8.0 / 3.0], 0.0, 1e-2)
+        for _ in range(2):
+            ctx.solve_fixed(np.arange(ns + 1) * dt); ctx.smooth()
+        f_ms, s_ms = ctx.kernel_time_ms(0)[0], ctx.kernel_time_ms(1)[0]
+        nb = (2 * 8 * (D + TRI + 1) - 8) * N * (ns - 1)
+        print(json.dumps({"mode": "smooth", "traj": N, "nsteps": ns, "filter_ms": f_ms, "smooth_ms": s_ms,
+                          "smoother_steps_per_s": N * (ns - 1) / (s_ms * 1e-3), "alg_GBps": nb / (s_ms * 1e-3) / 1e9}))
+        ctx.close()
+    elif mode == "adaptive":
+        ctx = pkg.Context("lorenz63", 3, 1, N, smooth=True)
+        ctx.set_problem_perturbed([1.0, 0.0, 0.0], [10.0, 28.0, 8.0 / 3.0], 0.0, 1e-2)
+        for _ in range(2):
+            ctx.solve_adaptive(ns * dt, 1e-6, 1e-3, dt, None, 1024); ctx.smooth()
+        f_ms, s_ms = ctx.kernel_time_ms(0)[0], ctx.kernel_time_ms(1)[0]
+        na, nr = ctx.get(5), ctx.get(6)
+        print(json.dumps({"mode": "adaptive", "traj": N, "t1": ns * dt, "filter_ms": f_ms, "smooth_ms": s_ms,
+                          "attempted_steps": int(na.sum() + nr.sum()), "accepted": int(na.sum()), "naccept_minmax": [int(na.min()), int(na.max())],
+                          "attempted_steps_per_s": float(na.sum() + nr.sum()) / (f_ms * 1e-3), "retcodes_ok": bool((ctx.get(10) == 0).all())}))
+        ctx.close()
