@@ -55,6 +55,9 @@ struct odef_ctx {
   long n_save = 0;
   bool adaptive = false;
   bool solved = false;
+  bool team_path = false;   // workgroup-per-trajectory kernels (large state dimension)
+  double* d_ws = nullptr;   // per-trajectory workspace of the team kernels
+  size_t ws_cap = 0;
   Buf f[ODEF_F_COUNT_];
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float ms[2] = {0.f, 0.f};
@@ -156,6 +159,16 @@ int ensure(odef_ctx* c, int field, size_t bytes) {
   return 0;
 }
 
+int ensure_ws(odef_ctx* c, size_t doubles) {
+  if (c->ws_cap >= doubles) return 0;
+  if (c->d_ws) HIPCHK(c, hipFree(c->d_ws));
+  c->d_ws = nullptr;
+  c->ws_cap = 0;
+  HIPCHK(c, hipMalloc((void**)&c->d_ws, doubles * sizeof(double)));
+  c->ws_cap = doubles;
+  return 0;
+}
+
 int set_device(odef_ctx* c) {
   HIPCHK(c, hipSetDevice(c->device));
   return 0;
@@ -233,7 +246,6 @@ int odef_create(odef_ctx** out, const odef_config* cfg) {
   if (cfg->diffusion != ODEF_DIFFUSION_DYNAMIC && cfg->diffusion != ODEF_DIFFUSION_FIXED)
     return fail(nullptr, "odef_create: unknown diffusion model %d", cfg->diffusion);
   if (cfg->n_traj <= 0) return fail(nullptr, "odef_create: n_traj must be positive");
-  if (cfg->rhs_id == ODEF_RHS_PLEIADES) return fail(nullptr, "odef_create: rhs PLEIADES (D=168 workgroup kernel) is not built yet");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, "odef_create: no HIP device available (libodefilter_hip has no CPU path)");
@@ -249,6 +261,7 @@ int odef_create(odef_ctx** out, const odef_config* cfg) {
   else if (hipGetDevice(&c->device) != hipSuccess) c->device = 0;
   if (c->device >= ndev) { delete c; return fail(nullptr, "odef_create: device %d not present (%d devices)", cfg->device, ndev); }
   build_prior(c->q, c->pc);
+  c->team_path = (cfg->rhs_id == ODEF_RHS_PLEIADES);
   hipError_t e = hipSetDevice(c->device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
   for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev[k]);
@@ -275,6 +288,7 @@ void odef_destroy(odef_ctx* c) {
     if (k != ODEF_F_U0 && c->f[k].owned && c->f[k].ptr) (void)hipFree(c->f[k].ptr);
   if (c->d_u0) (void)hipFree(c->d_u0);
   if (c->d_p) (void)hipFree(c->d_p);
+  if (c->d_ws) (void)hipFree(c->d_ws);
   if (c->d_hs) (void)hipFree(c->d_hs);
   if (c->d_ptab) (void)hipFree(c->d_ptab);
   if (c->d_tab_idx) (void)hipFree(c->d_tab_idx);
@@ -467,8 +481,19 @@ int odef_solve_fixed(odef_ctx* c, const double* tgrid, int64_t n_t) {
   P.tab_idx = c->d_tab_idx;
   P.nsteps = nsteps;
   P.t0 = c->t0;
-  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  const int rc = launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 0, P, c->stream);
+  int rc;
+  if (c->team_path) {
+    if (ensure_ws(c, (size_t)c->cfg.n_traj * team_filter_ws_doubles(c->d, c->q))) return -1;
+    TeamFilterParams TP{P, c->d_ws};
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    rc = launch_filter_pleiades(c->q, c->cfg.alg == ODEF_EK1, TP, c->stream);
+  } else {
+    // one lane per trajectory: the per-field buffer descriptors carry 32-bit sizes
+    if ((size_t)c->TRI * (size_t)c->cfg.n_traj * sizeof(double) >= (1ull << 31))
+      return fail(c, "odef_solve_fixed: n_traj * D(D+1)/2 * 8 bytes must stay below 2 GiB per save slot; shard the ensemble");
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    rc = launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 0, P, c->stream);
+  }
   if (rc) return fail(c, "odef_solve_fixed: no kernel for rhs %d order %d", c->cfg.rhs_id, c->q);
   return finish_filter(c, 1);
 }
@@ -481,6 +506,9 @@ int odef_solve_adaptive(odef_ctx* c, double t1, double abstol, double reltol, do
   if (!(dt0 > 0.0)) return fail(c, "odef_solve_adaptive: dt0 must be positive");
   if (max_steps < 1) return fail(c, "odef_solve_adaptive: max_steps must be >= 1");
   if (c->cfg.save_mode != ODEF_SAVE_EVERYSTEP) return fail(c, "odef_solve_adaptive: needs ODEF_SAVE_EVERYSTEP");
+  if (c->team_path) return fail(c, "odef_solve_adaptive: adaptive stepping is not built for the workgroup-per-trajectory path (rhs %d) yet", c->cfg.rhs_id);
+  if ((size_t)c->TRI * (size_t)c->cfg.n_traj * sizeof(double) >= (1ull << 31))
+    return fail(c, "odef_solve_adaptive: n_traj * D(D+1)/2 * 8 bytes must stay below 2 GiB per save slot; shard the ensemble");
   if (set_device(c)) return -1;
   c->adaptive = true;
   c->n_save = (long)max_steps + 1;
@@ -534,8 +562,9 @@ int odef_smooth(odef_ctx* c) {
     HIPCHK(c, hipMemsetAsync(S.smean, 0, c->f[ODEF_F_SMOOTH_MEAN].valid, c->stream));
     HIPCHK(c, hipMemsetAsync(S.scov, 0, c->f[ODEF_F_SMOOTH_COV_TRIL].valid, c->stream));
   }
+  if (c->team_path && ensure_ws(c, (size_t)c->cfg.n_traj * team_smooth_ws_doubles(c->d, c->q))) return -1;
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  const int rc = launch_smooth(c->d, c->q, S, c->stream);
+  const int rc = c->team_path ? launch_smooth_d28(c->q, S, c->d_ws, c->stream) : launch_smooth(c->d, c->q, S, c->stream);
   if (rc) return fail(c, "odef_smooth: no kernel for d %d order %d", c->d, c->q);
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   HIPCHK(c, hipGetLastError());

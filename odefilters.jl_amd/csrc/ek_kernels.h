@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dispatch.h"
+#include "smooth_team.h"
+#include "filter_team.h"
 #include "launch.h"
 
 namespace odef {
@@ -27,11 +29,47 @@ __global__ __launch_bounds__(kWave) void ek_filter_adaptive_kernel(const FilterP
   const long i0 = (long)blockIdx.x * kWave;
   if (i0 + threadIdx.x < P.N) filter_adaptive_lane<RHS, q, EK1>(P, i0, threadIdx.x);
 }
+// Smoother: 16-lane teams, 4 trajectories per wavefront, per-trajectory matrices in LDS.
+constexpr int kSmoothTeam = 16;
+constexpr int kSmoothTeamsPerBlock = kWave / kSmoothTeam;
 template <int d, int q>
 __global__ __launch_bounds__(kWave) void rts_smooth_kernel(const SmoothParams P) {
-  const long i = (long)blockIdx.x * kWave + threadIdx.x;
-  if (i < P.N) smooth_lane<d, q>(P, i);
+  using W = SmoothWs<d, q + 1>;
+  __shared__ double lds[kSmoothTeamsPerBlock * W::size];
+  const int team = threadIdx.x / kSmoothTeam, tid = threadIdx.x % kSmoothTeam;
+  const long i = (long)blockIdx.x * kSmoothTeamsPerBlock + team;
+  if (i < P.N) smooth_team_lane<d, q, kSmoothTeam>(P, i, tid, lds + team * W::size);
 }
+
+// Workgroup-per-trajectory kernels (large state dimension): 256 threads cooperate on one trajectory,
+// matrices in a per-trajectory global workspace.
+constexpr int kTeamBig = 256;
+template <class RHS, int q, bool EK1>
+__global__ __launch_bounds__(kTeamBig) void ek_filter_team_kernel(const TeamFilterParams TP) {
+  TeamFilter<RHS, q, EK1, kTeamBig>::run(TP, (long)blockIdx.x, (int)threadIdx.x);
+}
+template <int d, int q>
+__global__ __launch_bounds__(kTeamBig) void rts_smooth_team_kernel(const SmoothParams P, double* ws) {
+  smooth_team_lane<d, q, kTeamBig>(P, (long)blockIdx.x, (int)threadIdx.x, ws + (size_t)blockIdx.x * SmoothWs<d, q + 1>::size);
+}
+
+struct LaunchTeamFilter {
+  const TeamFilterParams& TP;
+  hipStream_t s;
+  template <class RHS, int q, bool EK1>
+  void operator()() {
+    hipLaunchKernelGGL((ek_filter_team_kernel<RHS, q, EK1>), dim3((unsigned)TP.fp.N), dim3(kTeamBig), 0, s, TP);
+  }
+};
+struct LaunchTeamSmooth {
+  const SmoothParams& P;
+  double* ws;
+  hipStream_t s;
+  template <int d, int q>
+  void operator()() {
+    hipLaunchKernelGGL((rts_smooth_team_kernel<d, q>), dim3((unsigned)P.N), dim3(kTeamBig), 0, s, P, ws);
+  }
+};
 
 struct LaunchFilter {
   const FilterParams& P;
@@ -49,7 +87,7 @@ struct LaunchSmooth {
   hipStream_t s;
   template <int d, int q>
   void operator()() {
-    const unsigned grid = (unsigned)((P.N + kWave - 1) / kWave);
+    const unsigned grid = (unsigned)((P.N + kSmoothTeamsPerBlock - 1) / kSmoothTeamsPerBlock);
     hipLaunchKernelGGL((rts_smooth_kernel<d, q>), dim3(grid), dim3(kWave), 0, s, P);
   }
 };

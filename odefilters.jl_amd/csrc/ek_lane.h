@@ -279,187 +279,4 @@ struct SmoothParams {
   int* retcode;
 };
 
-template <int d, int q>
-__device__ inline void smooth_lane(const SmoothParams& P, long i) {
-  constexpr int NB = q + 1, D = d * NB, TRI = D * (D + 1) / 2;
-  const long n = P.adaptive ? (long)P.nsaved[i] : P.n_save;
-  const size_t N = (size_t)P.N;
-  double ms[D], Cs[TRI];
-  // copy first and last (index 1 in Julia is never smoothed, src/smoothing.jl:11)
-  {
-    const long idx[2] = {0, n - 1};
-    for (int w = 0; w < 2; ++w) {
-      const long s = idx[w];
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        ms[k] = P.mean[((size_t)s * D + k) * N + i];
-        P.smean[((size_t)s * D + k) * N + i] = ms[k];
-      }
-#pragma unroll
-      for (int k = 0; k < TRI; ++k) {
-        Cs[k] = P.cov[((size_t)s * TRI + k) * N + i];
-        P.scov[((size_t)s * TRI + k) * N + i] = Cs[k];
-      }
-    }
-  }
-  bool nan_seen = false;
-  for (long s = n - 2; s >= 1; --s) {
-    double h;
-    double tabv[kTabStride];
-    if (P.adaptive) {
-      h = P.tsave[(size_t)(s + 1) * N + i] - P.tsave[(size_t)s * N + i];
-      if (h != 0.0) precond_fill<NB>(h, precond_val<q>(h), tabv);
-    } else {
-      h = P.hs[s];
-      const double* __restrict__ t = P.ptab + (size_t)P.tab_idx[s] * kTabStride;
-#pragma unroll
-      for (int J = 0; J < NB; ++J) {
-        tabv[kTabPJ + J] = t[kTabPJ + J];
-        tabv[kTabPIJ + J] = t[kTabPIJ + J];
-      }
-    }
-    if (h == 0.0) {  // src/smoothing.jl:13-16
-#pragma unroll
-      for (int k = 0; k < D; ++k) P.smean[((size_t)s * D + k) * N + i] = ms[k];
-#pragma unroll
-      for (int k = 0; k < TRI; ++k) P.scov[((size_t)s * TRI + k) * N + i] = Cs[k];
-      continue;
-    }
-    const double sigma2 = P.diff[(size_t)(s + 1) * N + i];
-    const double* pj = tabv + kTabPJ;
-    const double* pij = tabv + kTabPIJ;
-    double mt[D], Ct[TRI], mst[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      mt[k] = pj[k / d] * P.mean[((size_t)s * D + k) * N + i];
-      mst[k] = pj[k / d] * ms[k];
-    }
-#pragma unroll
-    for (int a = 0; a < D; ++a)
-#pragma unroll
-      for (int b = 0; b <= a; ++b) {
-        Ct[tri(a, b)] = (P.cov[((size_t)s * TRI + tri(a, b)) * N + i] * pj[a / d]) * pj[b / d];
-        // V = sigma2*Q + P Sigma^s_+ P  (kept in Cs)
-        double v = (Cs[tri(a, b)] * pj[a / d]) * pj[b / d];
-        if ((a % d) == (b % d)) v += sigma2 * P.pc.Qt[a / d][b / d];
-        Cs[tri(a, b)] = v;
-      }
-    // predict (src/smoothing.jl:38): m^- = A m,  B = A Ct A' + sigma2 Q,  Lp = chol(B)
-    double mp[D];
-#pragma unroll
-    for (int J = 0; J < NB; ++J)
-#pragma unroll
-      for (int a = 0; a < d; ++a) {
-        double t = mt[J * d + a];
-#pragma unroll
-        for (int j = J + 1; j < NB; ++j) t += P.pc.At[J][j] * mt[j * d + a];
-        mp[J * d + a] = t;
-      }
-    double T[D][D];  // T = A Ct ; (Ct A')[i][k] = T[k][i]
-#pragma unroll
-    for (int J = 0; J < NB; ++J)
-#pragma unroll
-      for (int a = 0; a < d; ++a)
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-          double t = Ct[symidx(J * d + a, k)];
-#pragma unroll
-          for (int j = J + 1; j < NB; ++j) t += P.pc.At[J][j] * Ct[symidx(j * d + a, k)];
-          T[J * d + a][k] = t;
-        }
-    double Lp[TRI];
-#pragma unroll
-    for (int a = 0; a < D; ++a)
-#pragma unroll
-      for (int K = 0; K < NB; ++K)
-#pragma unroll
-        for (int b = 0; b < d; ++b) {
-          const int j = K * d + b;
-          if (j > a) continue;
-          double t = T[a][j];
-#pragma unroll
-          for (int k = K + 1; k < NB; ++k) t += T[a][k * d + b] * P.pc.At[K][k];
-          if ((a % d) == b) t += sigma2 * P.pc.Qt[a / d][K];
-          Lp[tri(a, j)] = t;
-        }
-    int fixes = 0;
-    chol_packed<D>(Lp, fixes);
-    // G = Ct A' B^-1 (src/smoothing.jl:42-43): rows solve  B g' = T[:, i]
-    double G[D][D];
-#pragma unroll
-    for (int r = 0; r < D; ++r) {
-      double w[D];
-#pragma unroll
-      for (int k = 0; k < D; ++k) {  // forward: Lp w = y
-        double t = T[k][r];
-#pragma unroll
-        for (int c = 0; c < k; ++c) t -= Lp[tri(k, c)] * w[c];
-        w[k] = (Lp[tri(k, k)] != 0.0) ? t / Lp[tri(k, k)] : 0.0;
-      }
-#pragma unroll
-      for (int k = D - 1; k >= 0; --k) {  // backward: Lp' g = w
-        double t = w[k];
-#pragma unroll
-        for (int c = k + 1; c < D; ++c) t -= Lp[tri(c, k)] * G[r][c];
-        G[r][k] = (Lp[tri(k, k)] != 0.0) ? t / Lp[tri(k, k)] : 0.0;
-      }
-    }
-    // mean (src/smoothing.jl:44)
-    double mnew[D];
-#pragma unroll
-    for (int r = 0; r < D; ++r) {
-      double t = mt[r];
-#pragma unroll
-      for (int k = 0; k < D; ++k) t += G[r][k] * (mst[k] - mp[k]);
-      mnew[r] = t;
-    }
-    // F = I - G A
-    double F[D][D];
-#pragma unroll
-    for (int r = 0; r < D; ++r)
-#pragma unroll
-      for (int K = 0; K < NB; ++K)
-#pragma unroll
-        for (int b = 0; b < d; ++b) {
-          double t = 0.0;
-#pragma unroll
-          for (int J = 0; J <= K; ++J) t += G[r][J * d + b] * P.pc.At[J][K];
-          F[r][K * d + b] = ((r == K * d + b) ? 1.0 : 0.0) - t;
-        }
-    // Sigma^s = F Ct F' + G V G'
-    double X1[D][D], X2[D][D];
-#pragma unroll
-    for (int r = 0; r < D; ++r)
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-          t1 += F[r][c] * Ct[symidx(c, k)];
-          t2 += G[r][c] * Cs[symidx(c, k)];
-        }
-        X1[r][k] = t1;
-        X2[r][k] = t2;
-      }
-#pragma unroll
-    for (int a = 0; a < D; ++a)
-#pragma unroll
-      for (int b = 0; b <= a; ++b) {
-        double t = 0.0;
-#pragma unroll
-        for (int c = 0; c < D; ++c) t += X1[a][c] * F[b][c] + X2[a][c] * G[b][c];
-        Cs[tri(a, b)] = (t * pij[a / d]) * pij[b / d];  // un-precondition (src/smoothing.jl:26)
-      }
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      ms[k] = pij[k / d] * mnew[k];
-      nan_seen = nan_seen || !(ms[k] == ms[k]);
-      P.smean[((size_t)s * D + k) * N + i] = ms[k];
-    }
-#pragma unroll
-    for (int k = 0; k < TRI; ++k) P.scov[((size_t)s * TRI + k) * N + i] = Cs[k];
-  }
-  if (nan_seen) P.retcode[i] = 3;  // "NaNs after smoothing" (src/smoothing.jl:25)
-}
-
 }  // namespace odef

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ek_lane.h"
+#include "filter_team.h"
+#include "team.h"
 
 namespace odef {
 // returns 0, or -2 when (rhs, q) is not instantiated
@@ -15,4 +17,9 @@ int launch_filter_vanderpol(int q, int ek1, int adaptive, const FilterParams& P,
 int launch_filter_linear(int q, int ek1, int adaptive, const FilterParams& P, hipStream_t s);
 int launch_smooth_d2(int q, const SmoothParams& P, hipStream_t s);
 int launch_smooth_d3(int q, const SmoothParams& P, hipStream_t s);
+// workgroup-per-trajectory path (Pleiades, d = 28)
+int launch_filter_pleiades(int q, int ek1, const TeamFilterParams& TP, hipStream_t s);
+int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s);
+size_t team_filter_ws_doubles(int d, int q);
+size_t team_smooth_ws_doubles(int d, int q);
 }  // namespace odef

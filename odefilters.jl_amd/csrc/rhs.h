@@ -187,4 +187,55 @@ struct RhsLinear {  // test/convergence.jl:9-14, test/state_init.jl:12-17
   }
 };
 
+
+// Pleiades 7-body problem (Hairer et al. IVP test set): state (x1..7, y1..7, x'1..7, y'1..7), masses m_i = i,
+//   x_i'' = sum_{j != i} m_j (x_j - x_i) / r_ij^3.   BASELINE.json config 4 (d = 28, D = 168 at order 5).
+struct RhsPleiades {
+  static constexpr int d = 28, np = 0, id = 5;
+  template <class T>
+  __device__ static void f(const T (&u)[28], const double* /*p*/, T (&du)[28]) {
+    for (int i = 0; i < 7; ++i) {
+      du[i] = u[14 + i];
+      du[7 + i] = u[21 + i];
+    }
+    for (int i = 0; i < 7; ++i) {
+      T sx(0.0), sy(0.0);
+      for (int j = 0; j < 7; ++j) {
+        if (j == i) continue;
+        const T dx = u[j] - u[i];
+        const T dy = u[7 + j] - u[7 + i];
+        const T w = (j + 1.0) * inv_r3(dx * dx + dy * dy);
+        sx = sx + w * dx;
+        sy = sy + w * dy;
+      }
+      du[14 + i] = sx;
+      du[21 + i] = sy;
+    }
+  }
+  __device__ static void jac(const double (&u)[28], const double* /*p*/, double (&J)[28][28]) {
+    for (int a = 0; a < 28; ++a)
+      for (int b = 0; b < 28; ++b) J[a][b] = 0.0;
+    for (int i = 0; i < 7; ++i) {
+      J[i][14 + i] = 1.0;
+      J[7 + i][21 + i] = 1.0;
+    }
+    for (int i = 0; i < 7; ++i)
+      for (int j = 0; j < 7; ++j) {
+        if (j == i) continue;
+        const double mj = j + 1.0;
+        const double dx = u[j] - u[i], dy = u[7 + j] - u[7 + i];
+        const double r2 = dx * dx + dy * dy;
+        const double r3 = 1.0 / (r2 * sqrt(r2));
+        const double r5 = r3 / r2;
+        const double axx = mj * (r3 - 3.0 * dx * dx * r5);
+        const double axy = mj * (-3.0 * dx * dy * r5);
+        const double ayy = mj * (r3 - 3.0 * dy * dy * r5);
+        J[14 + i][j] += axx;      J[14 + i][i] -= axx;
+        J[14 + i][7 + j] += axy;  J[14 + i][7 + i] -= axy;
+        J[21 + i][j] += axy;      J[21 + i][i] -= axy;
+        J[21 + i][7 + j] += ayy;  J[21 + i][7 + i] -= ayy;
+      }
+  }
+};
+
 }  // namespace odef

@@ -1,0 +1,203 @@
+// Team-cooperative small dense algebra: TEAM threads work on ONE trajectory whose matrices
+// live in a shared workspace (LDS for small D).  Every routine is a sequence of phases of the
+// form "for (e = tid; e < n; e += TEAM) out[e] = f(inputs)" in which no thread reads what
+// another thread writes in the same phase, separated by `sync()`.
+//
+//   TEAM == 1    host emulation / single thread: phases run sequentially, sync is a no-op
+//   TEAM <= 64   sub-wave team (all teams of a wavefront run in lock step): sync is a
+//                wave-scope memory fence + scheduling barrier (LDS operations of one wave are
+//                performed in issue order, so no s_barrier is needed)
+//   TEAM  > 64   whole workgroup: __syncthreads()
+//
+// Matrices are dense row-major D x D (symmetric ones stored in full) with an ODD leading dimension
+// LD = D|1 so that the rows of a column access fall into distinct LDS banks.
+#pragma once
+#include "ek_math.h"
+
+namespace odef {
+
+template <int TEAM>
+struct Team {
+  int tid;
+  __device__ inline void sync() const {
+#ifndef ODEF_HOST_EMUL
+    if constexpr (TEAM > 64) {
+      __syncthreads();
+    } else if constexpr (TEAM > 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+#endif
+  }
+};
+
+#define ODEF_TEAM_FOR(e, n) for (int e = t.tid; e < (n); e += TEAM)
+
+__host__ __device__ constexpr int team_ld(int D) { return D | 1; }
+
+// Y = X A'   (A = At (x) I_d block upper triangular):  Y[r][(K,b)] = sum_{k>=K} X[r][(k,b)] At[K][k]
+template <int d, int NB, int TEAM>
+__device__ inline void team_mul_At(const Team<TEAM>& t, const PriorConsts& pc, const double* __restrict__ X, double* __restrict__ Y) {
+  constexpr int D = d * NB, LD = team_ld(D);
+  ODEF_TEAM_FOR(e, D * D) {
+    const int r = e / D, c = e % D, K = c / d, b = c % d;
+    double s = X[r * LD + c];
+    for (int k = K + 1; k < NB; ++k) s += X[r * LD + k * d + b] * pc.At[K][k];
+    Y[r * LD + c] = s;
+  }
+}
+
+// B = A Y + sigma2 Q   (full symmetric storage):  B[(J,a)][c] = sum_{j>=J} At[J][j] Y[(j,a)][c]
+template <int d, int NB, int TEAM>
+__device__ inline void team_A_mul_plusQ(const Team<TEAM>& t, const PriorConsts& pc, const double* __restrict__ Y, double sigma2,
+                                        double* __restrict__ B) {
+  constexpr int D = d * NB, LD = team_ld(D);
+  ODEF_TEAM_FOR(e, D * D) {
+    const int r = e / D, c = e % D, J = r / d, a = r % d;
+    double s = Y[r * LD + c];
+    for (int j = J + 1; j < NB; ++j) s += pc.At[J][j] * Y[(j * d + a) * LD + c];
+    if (a == c % d) s += sigma2 * pc.Qt[J][c / d];
+    B[r * LD + c] = s;
+  }
+}
+
+// In-place right-looking Cholesky of the first `ncols` columns of the full-storage symmetric X
+// (lower triangle is referenced and overwritten; the trailing block ends as the Schur complement).
+// A non-positive pivot zeroes its column (semi-definite rule, see ek_math.h).
+template <int D, int TEAM>
+__device__ inline void team_cholesky(const Team<TEAM>& t, double* __restrict__ X, int ncols) {
+  constexpr int LD = team_ld(D);
+  for (int k = 0; k < ncols; ++k) {
+    const double piv = X[k * LD + k];
+    const bool ok = piv > 0.0;
+    const double inv = ok ? 1.0 / piv : 0.0;
+    // trailing update with the unscaled column: X[i][j] -= X[i][k] X[j][k] / piv   (k < j <= i)
+    ODEF_TEAM_FOR(i, D) {
+      if (i > k) {
+        const double xik = X[i * LD + k] * inv;
+        for (int j = k + 1; j <= i; ++j) X[i * LD + j] -= xik * X[j * LD + k];
+      }
+    }
+    t.sync();
+    const double rs = ok ? 1.0 / sqrt(piv) : 0.0;
+    ODEF_TEAM_FOR(i, D) {
+      if (i > k) X[i * LD + k] *= rs;
+      else if (i == k) X[k * LD + k] = ok ? sqrt(piv) : 0.0;
+    }
+    t.sync();
+  }
+}
+
+// Rows of G solve  G (L L') = Y  in place (row-parallel):  g = y L^-T, then g = g L^-1.
+template <int D, int TEAM>
+__device__ inline void team_solve_right_spd(const Team<TEAM>& t, const double* __restrict__ L, double* __restrict__ G) {
+  constexpr int LD = team_ld(D);
+  ODEF_TEAM_FOR(r, D) {
+    double* g = G + r * LD;
+    for (int k = 0; k < D; ++k) {
+      double s = g[k];
+      for (int c = 0; c < k; ++c) s -= L[k * LD + c] * g[c];
+      const double lkk = L[k * LD + k];
+      g[k] = (lkk != 0.0) ? s / lkk : 0.0;
+    }
+    for (int k = D - 1; k >= 0; --k) {
+      double s = g[k];
+      for (int c = k + 1; c < D; ++c) s -= L[c * LD + k] * g[c];
+      const double lkk = L[k * LD + k];
+      g[k] = (lkk != 0.0) ? s / lkk : 0.0;
+    }
+  }
+}
+
+// One Rauch-Tung-Striebel step for one trajectory (src/smoothing.jl:31-63, src/filtering.jl:136-154).
+// Workspace `ws` (SmoothWs::size doubles): X | Y/G | M | vectors.  On entry X holds the filter covariance
+// of time i (full symmetric, un-preconditioned), `mf` its mean, M / `ms` the smoothed covariance /
+// mean of time i+1 (un-preconditioned).  On exit `ms` holds the smoothed mean of time i
+// (un-preconditioned) and M holds G (Sigma^s_+ - Sigma^-) G' in preconditioned coordinates: the caller
+// adds P Sigma P and un-preconditions (smooth_team_lane).
+//   G = Sigma A' (Sigma^-)^-1 by two triangular solves against chol(Sigma^-) (the reference inverts
+//   Sigma^- densely, src/squarerootmatrix.jl:42);
+//   Sigma^s = Sigma + G (Sigma^s_+ - Sigma^-) G'  -- the identity test/filtering.jl:113 asserts for the
+//   reference's stacked-QR Joseph form (src/smoothing.jl:53-57); both forms agree to the oracle's
+//   own rounding noise on every test problem.
+template <int d, int NB>
+struct SmoothWs {
+  static constexpr int D = d * NB, LD = team_ld(D), MAT = D * LD;
+  static constexpr int X = 0, Y = MAT, M = 2 * MAT, MF = 3 * MAT, MS = MF + D, MP = MS + D, DL = MP + D, used = DL + D;
+  // per-team stride: == 8 (mod 32) doubles, so the 4 teams of a wavefront start 16 banks apart
+  static constexpr int size = used + ((8 - used % 32) + 32) % 32;
+};
+
+template <int d, int NB, int TEAM>
+__device__ inline void team_smooth_step(const Team<TEAM>& t, const PriorConsts& pc, const double* __restrict__ tab, double sigma2,
+                                        double* __restrict__ ws) {
+  using W = SmoothWs<d, NB>;
+  constexpr int D = W::D, LD = W::LD;
+  double* X = ws + W::X;
+  double* Y = ws + W::Y;
+  double* M = ws + W::M;
+  double* mf = ws + W::MF;
+  double* ms = ws + W::MS;
+  double* mp = ws + W::MP;
+  double* dl = ws + W::DL;
+  // precondition x_i and x_{i+1}^s  (src/smoothing.jl:23-24)
+  ODEF_TEAM_FOR(e, D * D) {
+    const int r = e / D, c = e % D;
+    const double pp = tab[kTabPP + (r / d) * MAXNB + (c / d)];
+    X[r * LD + c] *= pp;
+    M[r * LD + c] *= pp;
+  }
+  ODEF_TEAM_FOR(i, D) {
+    mf[i] *= tab[kTabPJ + i / d];
+    ms[i] *= tab[kTabPJ + i / d];
+  }
+  t.sync();
+  // predict (src/smoothing.jl:38): m^- = A m ; Y = Sigma A' ; B = A Y + sigma2 Q
+  ODEF_TEAM_FOR(i, D) {
+    const int J = i / d, a = i % d;
+    double s = mf[i];
+    for (int j = J + 1; j < NB; ++j) s += pc.At[J][j] * mf[j * d + a];
+    mp[i] = s;
+  }
+  team_mul_At<d, NB, TEAM>(t, pc, X, Y);
+  t.sync();
+  // B = A Y + sigma2 Q (src/filtering.jl:34-35).  Only three D x D buffers are kept per trajectory, so
+  // B overwrites X (Sigma); the caller re-reads Sigma from the filter record for the final sum.
+  ODEF_TEAM_FOR(e, D * D) {
+    const int r = e / D, c = e % D, J = r / d, a = r % d;
+    double s = Y[r * LD + c];
+    for (int j = J + 1; j < NB; ++j) s += pc.At[J][j] * Y[(j * d + a) * LD + c];
+    if (a == c % d) s += sigma2 * pc.Qt[J][c / d];
+    M[r * LD + c] -= s;  // M = Sigma^s_+ - Sigma^-
+    X[r * LD + c] = s;   // X = Sigma^-  (Sigma itself is re-read by the caller)
+  }
+  ODEF_TEAM_FOR(i, D) dl[i] = ms[i] - mp[i];
+  t.sync();
+  team_cholesky<D, TEAM>(t, X, D);
+  // G = Y (Sigma^-)^-1, rows in place in Y  (src/smoothing.jl:42-43)
+  team_solve_right_spd<D, TEAM>(t, X, Y);
+  t.sync();
+  // mean (src/smoothing.jl:44) and T = G M  (into X, whose factor is no longer needed)
+  ODEF_TEAM_FOR(i, D) {
+    double s = mf[i];
+    for (int k = 0; k < D; ++k) s += Y[i * LD + k] * dl[k];
+    ms[i] = s * tab[kTabPIJ + i / d];  // un-precondition (src/smoothing.jl:26)
+  }
+  ODEF_TEAM_FOR(e, D * D) {
+    const int r = e / D, c = e % D;
+    double s = 0.0;
+    for (int k = 0; k < D; ++k) s += Y[r * LD + k] * M[k * LD + c];
+    X[r * LD + c] = s;
+  }
+  t.sync();
+  // M <- G M G' (the caller adds Sigma and un-preconditions)
+  ODEF_TEAM_FOR(e, D * D) {
+    const int r = e / D, c = e % D;
+    double s = 0.0;
+    for (int k = 0; k < D; ++k) s += X[r * LD + k] * Y[c * LD + k];
+    M[r * LD + c] = s;
+  }
+  t.sync();
+}
+
+}  // namespace odef

@@ -506,7 +506,7 @@ def solve(prob, alg, ensemblealg: EnsembleHIP = EnsembleHIP(), *, trajectories: 
     ctx = Context(base.f, alg.order, alg._id, N, diffusion=alg.diffusionmodel, smooth=alg.smooth,
                   save_everystep=save_everystep, params_shared=shared, device=ensemblealg.device,
                   want_loglik=want_loglik)
-    p = np.asarray(base.p, float) if shared else np.asarray(prob.ps, float)
+    p = np.asarray(base.p, float).reshape(-1) if shared else np.asarray(prob.ps, float)
     if prob.u0s is not None:
         ctx.set_problem(u0s, p, t0)
     else:

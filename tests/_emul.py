@@ -21,7 +21,7 @@ def build():
     src = os.path.join(HERE, "emul", "emul.cpp")
     out = os.path.join(HERE, "emul", "libodef_emul.so")
     deps = [src] + [os.path.join(ROOT, "odefilters.jl_amd", "csrc", f) for f in
-                    ("ek_math.h", "ek_lane.h", "rhs.h", "dispatch.h", "odef_platform.h")]
+                    ("ek_math.h", "ek_lane.h", "rhs.h", "dispatch.h", "odef_platform.h", "team.h", "smooth_team.h", "filter_team.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++20", "-shared", "-fPIC", "-Wno-unknown-pragmas", src, "-o", out])
     return out
@@ -84,7 +84,7 @@ def unpack_tril(c, D):
     return out
 
 
-def emul_solve(rhs_id, d, q, ek1, u0s, p, *, tgrid=None, adaptive=False, t0=0.0, t1=1.0, abstol=1e-6, reltol=1e-3,
+def emul_solve(rhs_id, d, q, ek1, u0s, p, *, team=False, tgrid=None, adaptive=False, t0=0.0, t1=1.0, abstol=1e-6, reltol=1e-3,
                dt0=1e-2, max_save=4096, everystep=True, fixed_diffusion=False, want_loglik=True, smooth=False,
                ctrl=None):
     """u0s [N, d]; p [np] shared.  Returns dict of numpy arrays in the device layout transposed
@@ -95,7 +95,7 @@ def emul_solve(rhs_id, d, q, ek1, u0s, p, *, tgrid=None, adaptive=False, t0=0.0,
     TRI = D * (D + 1) // 2
     At, Qt, QLt = prior_tables(q)
     u0_dev = np.ascontiguousarray(u0s.T)
-    p = np.ascontiguousarray(np.asarray(p, float))
+    p = np.ascontiguousarray(np.asarray(p, float)) if len(p) else np.zeros(1)
     if ctrl is None:
         ctrl = np.array([7.0 / (10 * (q + 1)), 2.0 / (5 * (q + 1)), 0.9, 0.2, 10.0, 1.0, 1.0, 1e-4, 0.0, 1e300])
     a = EmulArgs()
@@ -131,7 +131,7 @@ def emul_solve(rhs_id, d, q, ek1, u0s, p, *, tgrid=None, adaptive=False, t0=0.0,
     smean = np.zeros_like(mean) if smooth else np.zeros(1)
     scov = np.zeros_like(cov) if smooth else np.zeros(1)
     a.smean, a.scov, a.n_save = _p(smean), _p(scov), n_save
-    rc = lib().emul_filter(C.byref(a))
+    rc = (lib().emul_filter_team if team else lib().emul_filter)(C.byref(a))
     assert rc == 0, rc
     out = dict(mean=mean.transpose(2, 0, 1), cov=unpack_tril(cov.transpose(2, 0, 1), D), diff=diff.T, tsave=tsave.T,
                loglik=loglik, naccept=ints[0], nreject=ints[1], nf=ints[2], njac=ints[3], nsaved=ints[4],

@@ -4,6 +4,9 @@
 // library never loads this.
 #define ODEF_HOST_EMUL 1
 #include "../../odefilters.jl_amd/csrc/dispatch.h"
+#include "../../odefilters.jl_amd/csrc/smooth_team.h"
+#include "../../odefilters.jl_amd/csrc/filter_team.h"
+#include <vector>
 #include <cstring>
 
 using namespace odef;
@@ -59,7 +62,8 @@ struct RunSmooth {
   const SmoothParams& P;
   template <int d, int q>
   void operator()() {
-    for (long i = 0; i < P.N; ++i) smooth_lane<d, q>(P, i);
+    std::vector<double> ws(SmoothWs<d, q + 1>::size);
+    for (long i = 0; i < P.N; ++i) smooth_team_lane<d, q, 1>(P, i, 0, ws.data());
   }
 };
 
@@ -89,6 +93,7 @@ extern "C" int emul_smooth(const EmulArgs* a, int d) {
   RunSmooth r{P};
   if (d == 2) return dispatch_smooth_order<2>(a->q, r);
   if (d == 3) return dispatch_smooth_order<3>(a->q, r);
+  if (d == 28) return dispatch_smooth_order<28>(a->q, r);
   return -2;
 }
 
@@ -103,3 +108,25 @@ extern "C" void emul_precond_fill(int q, double h, double pval, double* tab) {
   }
 }
 extern "C" int emul_tab_stride() { return kTabStride; }
+
+// team (workgroup-per-trajectory) filter with TEAM = 1: Pleiades, and Lorenz-63 as a cross-check
+struct RunTeamFilter {
+  const FilterParams& P;
+  template <class RHS, int q, bool EK1>
+  void operator()() {
+    using TF = TeamFilter<RHS, q, EK1, 1>;
+    std::vector<double> ws((size_t)P.N * TF::W::size);
+    TeamFilterParams TP{P, ws.data()};
+    for (long i = 0; i < P.N; ++i) TF::run(TP, i, 0);
+  }
+};
+extern "C" int emul_filter_team(const EmulArgs* a) {
+  FilterParams P;
+  fill(*a, P);
+  RunTeamFilter r{P};
+  switch (a->rhs) {
+    case 1: return dispatch_order<RhsLorenz63>(a->q, a->ek1, r);
+    case 5: return dispatch_order<RhsPleiades>(a->q, a->ek1, r);
+    default: return -2;
+  }
+}

@@ -45,7 +45,22 @@ def run_case(name, rhs, alg, *, n_traj, scale, dt=None, tspan=None, adaptive=Fal
     print(name, "ok", out["mean_filt"].shape)
 
 
+def run_pleiades(name, n_traj=2, nsteps=24, q=5):
+    """BASELINE config 4 at test size: final filter state + u time series only (a full record is 226 KB per step)."""
+    vf = orc.vector_field("pleiades")
+    dt = 2.0**-10
+    u0s = orc.ensemble_u0(vf.u0, n_traj, 1e-3, n_perturbed=14)
+    mf, cf, us, df, ll = [], [], [], [], []
+    for i in range(n_traj):
+        sol = orc.solve(vf, orc.EK1(order=q, smooth=False), u0=u0s[i], tspan=(0.0, nsteps * dt), dt=dt)
+        mf.append(sol.x_filt[-1].mu); cf.append(sol.x_filt[-1].cov()); us.append(sol.u); df.append(sol.diffusions); ll.append(sol.log_likelihood)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), u0s=u0s, nsteps=nsteps, dt=dt, order=q, mean_final=np.array(mf),
+                        cov_final=np.array(cf).astype(np.float64), u=np.array(us), diffusions=np.array(df), loglik=np.array(ll))
+    print(name, "ok")
+
+
 if __name__ == "__main__":
+    run_pleiades("pleiades_ek1_q5_cfg4")
     # config 1 (BASELINE.json): FHN, EK0(order=1), single trajectory, dt = 7e-2, smooth
     run_case("fhn_ek0_q1_cfg1", "fhn", orc.EK0(order=1), n_traj=1, scale=0.0, dt=7e-2)
     # config 2/3 shape at test size: Lorenz-63 EK1(order=3), perturbed ensemble, dt = 2^-9

@@ -82,3 +82,34 @@ def test_final_only_save_mode():
     rf = E.emul_solve(vf.rhs_id, 2, 2, True, vf.u0[None, :], vf.p, tgrid=tg, everystep=False)
     np.testing.assert_array_equal(ra["mean"][0][-1], rf["mean"][0][0])
     np.testing.assert_array_equal(ra["cov"][0][-1], rf["cov"][0][0])
+
+
+def test_team_filter_matches_lane_filter_and_oracle():
+    """The workgroup-per-trajectory code path (filter_team.h, TEAM = 1 here) on Lorenz-63 against the
+    lane-per-trajectory path and the oracle."""
+    vf = orc.vector_field("lorenz63")
+    alg = orc.EK1(order=3)
+    tg = np.arange(129) * 2.0**-9
+    base, nm, nc = P.oracle_noise(vf, alg, vf.u0, dict(tspan=(0.0, tg[-1]), dt=2.0**-9), False)
+    rt = E.emul_solve(vf.rhs_id, 3, 3, True, vf.u0[None, :], vf.p, team=True, tgrid=tg)
+    rl = E.emul_solve(vf.rhs_id, 3, 3, True, vf.u0[None, :], vf.p, tgrid=tg)
+    P.check_against_oracle(rt["mean"][0], rt["cov"][0], base.means(smoothed=False), base.covs(smoothed=False), 3, nm, nc, "team")
+    np.testing.assert_allclose(rt["mean"][0][:, :3], rl["mean"][0][:, :3], rtol=1e-12)
+    np.testing.assert_allclose(rt["loglik"], rl["loglik"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("q,ek1", [(2, True), (3, False), (5, True)])
+def test_pleiades_team_filter(q, ek1):
+    """BASELINE config 4 problem (d = 28) through the team path: Taylor-mode init with r^-3 jets, filter, smoother."""
+    vf = orc.vector_field("pleiades")
+    alg = orc.Alg("EK1" if ek1 else "EK0", q, "dynamic", True)
+    ns = 10
+    sol = orc.solve(vf, alg, dt=2.0**-10, tspan=(0.0, ns * 2.0**-10))
+    r = E.emul_solve(vf.rhs_id, 28, q, ek1, vf.u0[None, :], vf.p, team=True, tgrid=np.array(sol.t), smooth=True)
+    M = sol.means(smoothed=False)
+    np.testing.assert_allclose(r["mean"][0][0], M[0], rtol=1e-13, atol=1e-13)  # Taylor-mode initial state
+    np.testing.assert_allclose(r["mean"][0][:, :28], M[:, :28], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(r["smean"][0][:, :28], sol.means(smoothed=True)[:, :28], rtol=1e-12, atol=1e-13)
+    assert r["retcode"][0] == 0
+    if q < 5:  # at order 5 the residual of the first steps is pure rounding noise in BOTH implementations
+        assert P.cov_err(r["cov"][0], sol.covs(smoothed=False)) < 1e-6

@@ -217,3 +217,50 @@ def test_caller_owned_output_buffers_and_stream(pkg):
     ms, nl = ctx.kernel_time_ms(0)
     assert ms > 0 and nl == 1
     ctx.close()
+
+
+# ---- BASELINE config 4: Pleiades, d = 28, EK1(order=5), D = 168 (workgroup-per-trajectory kernels) ----
+
+
+def test_pleiades_config4_golden(pkg):
+    g = np.load(os.path.join(GOLD, "pleiades_ek1_q5_cfg4.npz"))
+    vf = orc.vector_field("pleiades")
+    u0s, ns, dt = g["u0s"], int(g["nsteps"]), float(g["dt"])
+    prob = pkg.EnsembleProblem(pkg.ODEProblem("pleiades", u0s[0], (0.0, ns * dt), ()), u0s=u0s)
+    sol = pkg.solve(prob, pkg.EK1(order=5, smooth=False), pkg.EnsembleHIP(), dt=dt, adaptive=False)
+    assert sol.retcode == ["Success"] * len(u0s)
+    np.testing.assert_allclose(sol.u, g["u"], rtol=1e-11, atol=1e-13)
+    m = sol.x_filt_mean()
+    be = P.block_err(m[:, -1], g["mean_final"], 28)
+    assert be[0] < 1e-11 and be[1] < 1e-9, be
+    # final-only save mode gives the same last record
+    sol2 = pkg.solve(prob, pkg.EK1(order=5, smooth=False), pkg.EnsembleHIP(), dt=dt, adaptive=False, save_everystep=False)
+    np.testing.assert_array_equal(sol2.x_filt_mean()[:, 0], m[:, -1])
+    np.testing.assert_array_equal(sol2.x_filt_cov()[:, 0], sol.x_filt_cov()[:, -1])
+
+
+@pytest.mark.parametrize("q,kind", [(2, "EK1"), (3, "EK0"), (5, "EK1")])
+def test_pleiades_ensemble_parity(pkg, q, kind):
+    """Perturbed positions (1e-3, first 14 components) as in SURVEY 8(d) config 4, filter + smoother."""
+    vf = orc.vector_field("pleiades")
+    N, ns, dt = 5, 12, 2.0**-10
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("pleiades", vf.u0, (0.0, ns * dt), ()), perturb_scale=1e-3, n_perturbed=14)
+    sol = pkg.solve(ens, _alg(pkg, kind, q), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-3, n_perturbed=14)
+    np.testing.assert_array_equal(sol.ctx.get(13).T, u0s)
+    assert sol.retcode == ["Success"] * N
+    mf, ms = sol.x_filt_mean(), sol.x_smooth_mean()
+    for i in (0, 4):
+        ref = orc.solve(vf, orc.Alg(kind, q, "dynamic", True), u0=u0s[i], tspan=(0.0, ns * dt), dt=dt)
+        np.testing.assert_allclose(mf[i][:, :28], ref.means(smoothed=False)[:, :28], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(ms[i][:, :28], ref.means(smoothed=True)[:, :28], rtol=1e-11, atol=1e-13)
+        if q < 5:
+            assert P.cov_err(sol.x_filt_cov()[i], ref.covs(smoothed=False)) < 1e-6
+            assert P.cov_err(sol.x_smooth_cov()[i], ref.covs(smoothed=True)) < 1e-6
+
+
+def test_pleiades_adaptive_is_rejected_loudly(pkg):
+    vf = orc.vector_field("pleiades")
+    prob = pkg.EnsembleProblem(pkg.ODEProblem("pleiades", vf.u0, (0.0, 0.01), ()), u0s=vf.u0[None, :])
+    with pytest.raises(pkg.OdefError, match="adaptive stepping is not built"):
+        pkg.solve(prob, pkg.EK1(order=3), pkg.EnsembleHIP(), adaptive=True, dt=1e-3)
