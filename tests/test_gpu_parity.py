@@ -250,13 +250,16 @@ def test_pleiades_ensemble_parity(pkg, q, kind):
     np.testing.assert_array_equal(sol.ctx.get(13).T, u0s)
     assert sol.retcode == ["Success"] * N
     mf, ms = sol.x_filt_mean(), sol.x_smooth_mean()
+    alg_o = orc.Alg(kind, q, "dynamic", True)
     for i in (0, 4):
-        ref = orc.solve(vf, orc.Alg(kind, q, "dynamic", True), u0=u0s[i], tspan=(0.0, ns * dt), dt=dt)
+        ref = orc.solve(vf, alg_o, u0=u0s[i], tspan=(0.0, ns * dt), dt=dt)
         np.testing.assert_allclose(mf[i][:, :28], ref.means(smoothed=False)[:, :28], rtol=1e-11, atol=1e-13)
         np.testing.assert_allclose(ms[i][:, :28], ref.means(smoothed=True)[:, :28], rtol=1e-11, atol=1e-13)
-        if q < 5:
-            assert P.cov_err(sol.x_filt_cov()[i], ref.covs(smoothed=False)) < 1e-6
-            assert P.cov_err(sol.x_smooth_cov()[i], ref.covs(smoothed=True)) < 1e-6
+        if q < 5:  # at order 5 the first steps' residuals are rounding noise in both implementations
+            for smoothed, m, c in ((False, mf, sol.x_filt_cov()), (True, ms, sol.x_smooth_cov())):
+                base, nm, nc = P.oracle_noise(vf, alg_o, u0s[i], dict(tspan=(0.0, ns * dt), dt=dt), smoothed)
+                P.check_against_oracle(m[i], c[i], base.means(smoothed=smoothed), base.covs(smoothed=smoothed), 28, nm, nc,
+                                       f"pleiades {kind}({q}) traj {i} smoothed={smoothed}")
 
 
 def test_pleiades_adaptive_is_rejected_loudly(pkg):
