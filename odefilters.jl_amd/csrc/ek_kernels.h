@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include "dispatch.h"
 #include "smooth_team.h"
+#include "smooth_rows.h"
 #include "filter_team.h"
 #include "launch.h"
 
@@ -29,18 +30,20 @@ __global__ __launch_bounds__(kWave) void ek_filter_adaptive_kernel(const FilterP
   const long i0 = (long)blockIdx.x * kWave;
   if (i0 + threadIdx.x < P.N) filter_adaptive_lane<RHS, q, EK1>(P, i0, threadIdx.x);
 }
-// Smoother: 16-lane teams, 4 trajectories per wavefront, per-trajectory matrices in LDS.
-constexpr int kSmoothTeam = 16;
-constexpr int kSmoothTeamsPerBlock = kWave / kSmoothTeam;
+// Smoother: row-per-lane teams (smooth_rows.h), 16 lanes per trajectory for D <= 16 (4 trajectories per
+// wavefront), 32 lanes for D <= 32; per-team matrices in LDS.
+template <int D>
+struct SmoothTeam { static constexpr int lanes = (D <= 16) ? 16 : 32; };
 template <int d, int q>
-__global__ __launch_bounds__(kWave) void rts_smooth_kernel(const SmoothParams P) {
-  using W = SmoothWs<d, q + 1>;
-  __shared__ double lds[kSmoothTeamsPerBlock * W::size];
-  const int team = threadIdx.x / kSmoothTeam, tid = threadIdx.x % kSmoothTeam;
-  const long i = (long)blockIdx.x * kSmoothTeamsPerBlock + team;
-  if (i < P.N) smooth_team_lane<d, q, kSmoothTeam>(P, i, tid, lds + team * W::size);
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_num_vgpr(128))) void rts_smooth_kernel(const SmoothParams P) {
+  constexpr int D = d * (q + 1), TEAM = SmoothTeam<D>::lanes, TPB = kWave / TEAM;
+  using W = RowsWs<d, q + 1>;
+  __shared__ double lds[TPB * W::size];
+  const int team = threadIdx.x / TEAM, tid = threadIdx.x % TEAM;
+  const long i = (long)blockIdx.x * TPB + team;
+  RowState<D> st;
+  if (i < P.N) smooth_rows_lane<d, q, TEAM>(P, i, tid, lds + team * W::size, &st);
 }
-
 // Workgroup-per-trajectory kernels (large state dimension): 256 threads cooperate on one trajectory,
 // matrices in a per-trajectory global workspace.
 constexpr int kTeamBig = 256;
@@ -87,7 +90,8 @@ struct LaunchSmooth {
   hipStream_t s;
   template <int d, int q>
   void operator()() {
-    const unsigned grid = (unsigned)((P.N + kSmoothTeamsPerBlock - 1) / kSmoothTeamsPerBlock);
+    constexpr int TPB = kWave / SmoothTeam<d * (q + 1)>::lanes;
+    const unsigned grid = (unsigned)((P.N + TPB - 1) / TPB);
     hipLaunchKernelGGL((rts_smooth_kernel<d, q>), dim3(grid), dim3(kWave), 0, s, P);
   }
 };

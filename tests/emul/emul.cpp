@@ -5,6 +5,7 @@
 #define ODEF_HOST_EMUL 1
 #include "../../odefilters.jl_amd/csrc/dispatch.h"
 #include "../../odefilters.jl_amd/csrc/smooth_team.h"
+#include "../../odefilters.jl_amd/csrc/smooth_rows.h"
 #include "../../odefilters.jl_amd/csrc/filter_team.h"
 #include <vector>
 #include <cstring>
@@ -62,8 +63,15 @@ struct RunSmooth {
   const SmoothParams& P;
   template <int d, int q>
   void operator()() {
-    std::vector<double> ws(SmoothWs<d, q + 1>::size);
-    for (long i = 0; i < P.N; ++i) smooth_team_lane<d, q, 1>(P, i, 0, ws.data());
+    if constexpr (d * (q + 1) <= 32) {  // row-per-lane teams: all lanes of a team emulated phase by phase
+      constexpr int D = d * (q + 1), TEAM = (D <= 16) ? 16 : 32;
+      std::vector<double> ws(RowsWs<d, q + 1>::size);
+      std::vector<RowState<D>> st(TEAM);
+      for (long i = 0; i < P.N; ++i) smooth_rows_lane<d, q, TEAM>(P, i, 0, ws.data(), st.data());
+    } else {
+      std::vector<double> ws(SmoothWs<d, q + 1>::size);
+      for (long i = 0; i < P.N; ++i) smooth_team_lane<d, q, 1>(P, i, 0, ws.data());
+    }
   }
 };
 

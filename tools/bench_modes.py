@@ -36,3 +36,17 @@ for mode in args.modes.split(","):
                           "attempted_steps": int(na.sum() + nr.sum()), "accepted": int(na.sum()), "naccept_minmax": [int(na.min()), int(na.max())],
                           "attempted_steps_per_s": float(na.sum() + nr.sum()) / (f_ms * 1e-3), "retcodes_ok": bool((ctx.get(10) == 0).all())}))
         ctx.close()
+if "pleiades" in args.modes.split(","):
+    u0 = [3.0, 3.0, -1.0, -3.0, 2.0, -2.0, 2.0, 3.0, -3.0, 2.0, 0.0, 0.0, -4.0, 4.0,
+          0.0, 0.0, 0.0, 0.0, 0.0, 1.75, -1.5, 0.0, 0.0, 0.0, -1.25, 1.0, 0.0, 0.0]
+    nsp = min(ns, 256)
+    ctx = pkg.Context("pleiades", 5, 1, N, save_everystep=False)
+    ctx.set_problem_perturbed(u0, [], 0.0, 1e-3, n_perturbed=14)
+    for _ in range(2):
+        ctx.solve_fixed(np.arange(nsp + 1) * 2.0**-10)
+    f_ms = ctx.kernel_time_ms(0)[0]
+    D = 168
+    F_alg = (16 / 3) * D**3 + 8 * 28 * D**2 + 4 * D**2
+    print(json.dumps({"mode": "pleiades", "traj": N, "nsteps": nsp, "filter_ms": f_ms, "steps_per_s": N * nsp / (f_ms * 1e-3),
+                      "F_alg_TFLOPs": F_alg * N * nsp / (f_ms * 1e-3) / 1e12, "retcodes_ok": bool((ctx.get(10) == 0).all())}))
+    ctx.close()
