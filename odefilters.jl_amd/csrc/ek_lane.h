@@ -53,19 +53,21 @@ struct FilterParams {
 struct RowStore {
   double* p;
   size_t n;
-  RowStore(double* base, size_t N, size_t /*rows*/, unsigned lane) : p(base + lane), n(N) {}
-  void put(double v) { *p = v; p += n; }
+  bool on;
+  RowStore(double* base, size_t N, size_t /*rows*/, unsigned lane, bool enabled = true) : p(base + lane), n(N), on(enabled) {}
+  void put(double v) { if (on) { *p = v; p += n; } }
 };
 #else
 struct RowStore {
   __amdgpu_buffer_rsrc_t rs;
   unsigned voff, soff, step;
-  __device__ RowStore(double* base, size_t N, size_t rows, unsigned lane)
+  bool on;  // wave-uniform
+  __device__ RowStore(double* base, size_t N, size_t rows, unsigned lane, bool enabled = true)
       : rs(__builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(rows * N * sizeof(double)), 0x00020000)),
-        voff(lane * 8u), soff(0u), step((unsigned)(N * sizeof(double))) {}
+        voff(lane * 8u), soff(0u), step((unsigned)(N * sizeof(double))), on(enabled) {}
   __device__ void put(double v) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, 0);
+    if (on) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, 0);
     soff += step;
     asm volatile("" : "+s"(soff));  // keep the row offset a running scalar (one s_add per store) instead of
                                     // dozens of hoisted loop-invariant offsets that would spill the SGPR file
@@ -88,6 +90,13 @@ __device__ inline void store_state(const FilterParams& P, long slot, long i0, un
   RowStore sd(P.diff + ((size_t)slot * N + i0), N, 1, lane);
   sd.put(diffusion);
 }
+
+// Sink of EKStep::run that stores each value of the step's record as soon as it exists.
+struct RecordSink {
+  RowStore sm, sc;
+  __device__ inline void mean(double v) { sm.put(v); }
+  __device__ inline void cov(double v) { sc.put(v); }
+};
 
 template <int D>
 __device__ inline bool all_finite(const double (&m)[D]) {
@@ -122,7 +131,10 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigne
     double m2[D], C2[TRI], es[d];
     StepAux aux;
     aux.chol_fix = 0;
-    S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux);
+    const size_t Nn = (size_t)P.N;
+    RecordSink sink{RowStore(P.mean + ((size_t)(n + 1) * D * Nn + i0), Nn, D, lane, P.everystep != 0),
+                    RowStore(P.cov + ((size_t)(n + 1) * TRI * Nn + i0), Nn, TRI, lane, P.everystep != 0)};
+    S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux, sink);
 #pragma unroll
     for (int k = 0; k < D; ++k) m[k] = m2[k];
 #pragma unroll
@@ -130,7 +142,10 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigne
     loglik += aux.loglik;
     gdiff = aux.sigma2_global;
     chol_fix += aux.chol_fix;
-    if (P.everystep) store_state<D, TRI>(P, n + 1, i0, lane, m, C, gdiff);
+    if (P.everystep) {
+      RowStore sd(P.diff + ((size_t)(n + 1) * Nn + i0), Nn, 1, lane);
+      sd.put(gdiff);
+    }
   }
   if (!P.everystep) store_state<D, TRI>(P, 0, i0, lane, m, C, gdiff);
   P.loglik[i] = loglik;
@@ -152,8 +167,36 @@ __device__ inline double precond_val(double h) {
   return 1.0 / (hq * sqrt(h));
 }
 
+// Per-lane (non-uniform slot) record store / reload for the adaptive filter: plain global accesses with
+// per-lane addresses (a buffer descriptor built from a lane-varying slot would be waterfalled per store).
+template <int D, int TRI>
+__device__ inline void store_state_scatter(const FilterParams& P, long slot, long i, const double (&m)[D],
+                                           const double (&C)[TRI], double diffusion, double t) {
+  const size_t N = (size_t)P.N;
+  double* pm = P.mean + ((size_t)slot * D * N + i);
+#pragma unroll
+  for (int k = 0; k < D; ++k) { *pm = m[k]; pm += N; }
+  double* pcv = P.cov + ((size_t)slot * TRI * N + i);
+#pragma unroll
+  for (int k = 0; k < TRI; ++k) { *pcv = C[k]; pcv += N; }
+  P.diff[(size_t)slot * N + i] = diffusion;
+  P.tsave[(size_t)slot * N + i] = t;
+}
+template <int D, int TRI>
+__device__ inline void load_state_scatter(const FilterParams& P, long slot, long i, double (&m)[D], double (&C)[TRI]) {
+  const size_t N = (size_t)P.N;
+  const double* pm = P.mean + ((size_t)slot * D * N + i);
+#pragma unroll
+  for (int k = 0; k < D; ++k) { m[k] = *pm; pm += N; }
+  const double* pcv = P.cov + ((size_t)slot * TRI * N + i);
+#pragma unroll
+  for (int k = 0; k < TRI; ++k) { C[k] = *pcv; pcv += N; }
+}
+
 // Adaptive filter: perform_step! + error estimate (src/perform_step.jl:78-92) + the PI
 // controller of OrdinaryDiffEq (third-party; exponents src/alg_utils.jl:23-24).
+// Only ONE copy of the state is kept in registers: the candidate x_filt overwrites it, and the rare
+// rejected step re-reads the previous accepted state from its save slot (every accepted state is saved).
 template <class RHS, int q, bool IS_EK1>
 __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsigned lane) {
   const long i = i0 + lane;
@@ -170,8 +213,7 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
   taylor_init<RHS, q>(u0, pl, m);
 #pragma unroll
   for (int k = 0; k < TRI; ++k) C[k] = 0.0;
-  store_state<D, TRI>(P, 0, i0, lane, m, C, 0.0);
-  P.tsave[i] = P.t0;
+  store_state_scatter<D, TRI>(P, 0, i, m, C, 0.0, P.t0);
 
   double ucur[d];
 #pragma unroll
@@ -190,21 +232,29 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
     if (!(h > ct.dtmin)) { ret = 2; break; }  // DtLessThanMin
     double tab[kTabStride];
     precond_fill<NB>(h, precond_val<q>(h), tab);
-    double m2[D], C2[TRI], es[d];
+    double es[d];
     StepAux aux;
     aux.chol_fix = 0;
-    S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, naccept, gdiff, m, C, m2, C2, es, aux);
+    {
+      double m2[D], C2[TRI];
+      NoSink nosink;
+      S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, naccept, gdiff, m, C, m2, C2, es, aux, nosink);
+#pragma unroll
+      for (int k = 0; k < D; ++k) m[k] = m2[k];
+#pragma unroll
+      for (int k = 0; k < TRI; ++k) C[k] = C2[k];
+    }
     // DiffEqBase.calculate_residuals! + ODE_DEFAULT_NORM (src/perform_step.jl:78-84)
     double acc = 0.0;
 #pragma unroll
     for (int r = 0; r < d; ++r) {
-      const double e = h * es[r] / (P.abstol + fmax(fabs(ucur[r]), fabs(m2[r])) * P.reltol);
+      const double e = h * es[r] / (P.abstol + fmax(fabs(ucur[r]), fabs(m[r])) * P.reltol);
       acc += e * e;
     }
     double EEst = sqrt(acc / d);
     if (!(EEst == EEst) || !(fabs(EEst) <= 1.79769313486231570815e+308)) EEst = INFINITY;
 #pragma unroll
-    for (int r = 0; r < d; ++r) ucur[r] = m2[r];  // integ.u .= u_filt (src/perform_step.jl:86), also when rejected
+    for (int r = 0; r < d; ++r) ucur[r] = m[r];  // integ.u .= u_filt (src/perform_step.jl:86), also when rejected
     // stepsize_controller! (PI)
     double qq;
     if (EEst == 0.0) {
@@ -214,20 +264,15 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
       qq = q11 / pow(qold, ct.beta2);
       qq = fmax(1.0 / ct.qmax, fmin(1.0 / ct.qmin, qq / ct.gamma));
     }
-    // cache.x after the attempt when x_filt is not committed: PI*(P*x) (src/perform_step.jl:73)
-    const double* pj = tab + kTabPJ;
-    const double* pij = tab + kTabPIJ;
-    if (EEst <= 1.0) {  // accepted by OrdinaryDiffEq
-      if (EEst < 1.0) {  // src/perform_step.jl:89
+    const bool accepted = EEst <= 1.0;  // OrdinaryDiffEq accepts on <=
+    if (!(EEst < 1.0)) {
+      // x_filt is not committed (src/perform_step.jl:89): cache.x stays P^-1 (P x) of the old state (:73)
+      load_state_scatter<D, TRI>(P, nsaved - 1, i, m, C);
 #pragma unroll
-        for (int k = 0; k < D; ++k) m[k] = m2[k];
-#pragma unroll
-        for (int k = 0; k < TRI; ++k) C[k] = C2[k];
-        loglik += aux.loglik;
-      } else {
-#pragma unroll
-        for (int k = 0; k < D; ++k) m[k] = pij[k / d] * (pj[k / d] * m[k]);
-      }
+      for (int k = 0; k < D; ++k) m[k] = tab[kTabPIJ + k / d] * (tab[kTabPJ + k / d] * m[k]);
+    }
+    if (accepted) {
+      if (EEst < 1.0) loglik += aux.loglik;
       if (qq <= ct.qsteady_max && qq >= ct.qsteady_min) qq = 1.0;
       qold = fmax(EEst, ct.qoldinit);
       double tn = t + h;
@@ -235,14 +280,11 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
       t = tn;
       gdiff = aux.sigma2_global;
       ++naccept;
-      store_state<D, TRI>(P, nsaved, i0, lane, m, C, gdiff);
-      P.tsave[(size_t)nsaved * P.N + i] = t;
+      store_state_scatter<D, TRI>(P, nsaved, i, m, C, gdiff, t);
       ++nsaved;
       h = h / qq;
       if (!all_finite<D>(m)) { ret = 3; break; }
     } else {
-#pragma unroll
-      for (int k = 0; k < D; ++k) m[k] = pij[k / d] * (pj[k / d] * m[k]);
       ++nreject;
       h = h / fmin(1.0 / ct.qmin, q11 / ct.gamma);
     }

@@ -241,10 +241,14 @@ struct EKStep {
   // out as the orthogonal transformation that triangularises (H L)': with (H L1)' = Q [R; 0],
   //   K = (L1 Q)[:, :d] R^-T,   Sigma_filt = (L1 Q)[:, d:2d] (L1 Q)[:, d:2d]' + Schur complement,
   // which is the Gram matrix of (I - K H) L without ever forming K H.
+  // `sink.mean(v)` / `sink.cov(v)` receive the un-preconditioned results in storage order as soon as each
+  // value exists, so that a caller that saves every step can issue its stores inside the final loops
+  // instead of in one burst after the step.
+  template <class Sink>
   __device__ static inline void run(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab,
                                     bool fixed_diffusion, bool want_loglik, int success_iter, double prev_global,
                                     const double (&m)[D], const double (&C)[TRI], double (&m_out)[D],
-                                    double (&C_out)[TRI], double (&err_scale)[d], StepAux& aux) {
+                                    double (&C_out)[TRI], double (&err_scale)[d], StepAux& aux, Sink& sink) {
     // x~ = P x  (src/perform_step.jl:36-38)
     double mt[D];
 #pragma unroll
@@ -453,6 +457,7 @@ struct EKStep {
 #pragma unroll
       for (int r = 0; r < d; ++r) t -= w[r] * y[r];
       m_out[l] = tab[kTabPIJ + l / d] * t;  // un-precondition (src/perform_step.jl:75)
+      sink.mean(m_out[l]);
 #pragma unroll
       for (int r = 0; r < d; ++r) Zp[l][r] = w[d + r];
     }
@@ -465,8 +470,14 @@ struct EKStep {
 #pragma unroll
         for (int r = 0; r < d; ++r) s += Zp[i][r] * Zp[j][r];
         C_out[tri(i, j)] = s * tab[kTabPIPI + (i / d) * MAXNB + (j / d)];
+        sink.cov(C_out[tri(i, j)]);
       }
   }
+};
+
+struct NoSink {
+  __device__ inline void mean(double) {}
+  __device__ inline void cov(double) {}
 };
 
 // Taylor-mode initialisation (src/state_initialization.jl:2-53): m0 = [u0; u'(t0); ...; u^(q)(t0)],
