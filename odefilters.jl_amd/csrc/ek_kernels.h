@@ -6,6 +6,7 @@
 #include "dispatch.h"
 #include "smooth_team.h"
 #include "smooth_rows.h"
+#include "smooth_lane.h"
 #include "filter_team.h"
 #include "launch.h"
 
@@ -44,6 +45,18 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_num_vgpr(128))) void r
   RowState<D> st;
   if (i < P.N) smooth_rows_lane<d, q, TEAM>(P, i, tid, lds + team * W::size, &st);
 }
+// Smoother, one lane per trajectory (D <= 12): the read-only filter covariance of the step sits in
+// lane-private LDS (78 doubles x 64 lanes = 39 KB per wave at D = 12), everything else in registers.
+constexpr int kSmoothLaneMaxD = 12;
+template <int d, int q>
+__global__ __launch_bounds__(kWave) void rts_smooth_lane_kernel(const SmoothParams P) {
+  constexpr int D = d * (q + 1), TRI = D * (D + 1) / 2;
+  __shared__ double lds[TRI * kWave];
+  const long i0 = (long)blockIdx.x * kWave;
+  const LaneMem xl{lds + threadIdx.x, kWave};
+  if (i0 + threadIdx.x < P.N) smooth_lane_v2<d, q>(P, i0, threadIdx.x, xl);
+}
+
 // Workgroup-per-trajectory kernels (large state dimension): 256 threads cooperate on one trajectory,
 // matrices in a per-trajectory global workspace.
 constexpr int kTeamBig = 256;
@@ -90,9 +103,14 @@ struct LaunchSmooth {
   hipStream_t s;
   template <int d, int q>
   void operator()() {
-    constexpr int TPB = kWave / SmoothTeam<d * (q + 1)>::lanes;
-    const unsigned grid = (unsigned)((P.N + TPB - 1) / TPB);
-    hipLaunchKernelGGL((rts_smooth_kernel<d, q>), dim3(grid), dim3(kWave), 0, s, P);
+    if constexpr (d * (q + 1) <= kSmoothLaneMaxD) {
+      const unsigned grid = (unsigned)((P.N + kWave - 1) / kWave);
+      hipLaunchKernelGGL((rts_smooth_lane_kernel<d, q>), dim3(grid), dim3(kWave), 0, s, P);
+    } else {
+      constexpr int TPB = kWave / SmoothTeam<d * (q + 1)>::lanes;
+      const unsigned grid = (unsigned)((P.N + TPB - 1) / TPB);
+      hipLaunchKernelGGL((rts_smooth_kernel<d, q>), dim3(grid), dim3(kWave), 0, s, P);
+    }
   }
 };
 

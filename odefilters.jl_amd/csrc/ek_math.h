@@ -13,6 +13,14 @@
 #include "odef_platform.h"
 #include "rhs.h"
 
+// Scheduling fence: keeps the instruction scheduler from hoisting every load of a fully unrolled loop
+// nest to the top (which costs hundreds of registers).  No code is emitted.
+#ifdef ODEF_HOST_EMUL
+#define ODEF_SCHED_FENCE()
+#else
+#define ODEF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace odef {
 
 constexpr int MAXNB = 6;  // order <= 5
@@ -24,6 +32,16 @@ struct PriorConsts {
   double Qt[MAXNB][MAXNB];
   double QLt[MAXNB][MAXNB];
 };
+
+// Compile-time loop: body(std::integral_constant<int, k>) for k = B .. E-1.  Used where `#pragma unroll`
+// gives up ("unrolled size too large") and the fallback run-time loop would index register arrays dynamically.
+template <int B, int E, class F>
+__device__ inline void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
 
 __host__ __device__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
 __host__ __device__ constexpr int symidx(int i, int j) { return i >= j ? tri(i, j) : tri(j, i); }

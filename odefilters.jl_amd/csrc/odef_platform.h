@@ -13,3 +13,4 @@ using std::fabs; using std::fmax; using std::fmin; using std::sqrt; using std::p
 #include <hip/hip_runtime.h>
 #endif
 #include <math.h>
+#include <type_traits>

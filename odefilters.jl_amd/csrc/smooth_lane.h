@@ -1,0 +1,266 @@
+// RTS smoother, one lane per trajectory (small D: packed covariance <= ~80 doubles).
+// src/smoothing.jl:4-63.  In preconditioned coordinates, with X = filter covariance of time i,
+//   B = A X A' + sigma2 Q = L L'            (predict, src/smoothing.jl:38)
+//   Z = B^-1 (S^s_+ - B) B^-1               (two in-place two-sided triangular transforms)
+//   W = A' Z A                              (in-place block congruence)
+//   m^s = m + X A' B^-1 (m^s_+ - A m)       (src/smoothing.jl:44, G = X A' B^-1 never formed)
+//   S^s = X + X W X                         ( = X + G (S^s_+ - B) G', test/filtering.jl:113 )
+// so no dense D x D matrix (G, I - G A) is ever live: the working set is three packed symmetric
+// matrices, one of which (X, read-only) sits in lane-private LDS ([element][lane]: conflict-free,
+// immediate-offset ds_read_b64).  78 doubles x 64 lanes x 8 B = 39 KB per wave at D = 12, so four
+// waves (one per SIMD) fill the 160 KB of a CU exactly.
+#pragma once
+#include "ek_lane.h"
+
+namespace odef {
+
+// lane-private array in LDS (device: base = lds + lane, stride = 64) or plain memory (host: stride 1)
+struct LaneMem {
+  double* base;
+  int stride;
+  __device__ inline double get(int k) const { return base[k * stride]; }
+  __device__ inline void set(int k, double v) const { base[k * stride] = v; }
+};
+
+// S <- L^-1 S L^-T  then  S <- L^-T S L^-1   (packed lower symmetric S, packed lower Cholesky factor L)
+template <int D>
+__device__ inline void two_sided_inverse(double (&S)[D * (D + 1) / 2], const double (&L)[D * (D + 1) / 2]) {
+  // forward: elementary congruences with L_k^-1
+  static_for<0, D>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const double lkk = L[tri(k, k)];
+    const double inv = (lkk != 0.0) ? 1.0 / lkk : 0.0;
+    const double tkk = S[tri(k, k)] * inv * inv;
+    S[tri(k, k)] = tkk;
+#pragma unroll
+    for (int j = 0; j < k; ++j) S[tri(k, j)] *= inv;
+    double b[D];
+#pragma unroll
+    for (int i = k + 1; i < D; ++i) {
+      const double a = S[tri(i, k)] * inv;
+      const double lik = L[tri(i, k)];
+      b[i] = a - 0.5 * lik * tkk;
+#pragma unroll
+      for (int j = 0; j < k; ++j) S[tri(i, j)] -= lik * S[tri(k, j)];
+    }
+#pragma unroll
+    for (int i = k + 1; i < D; ++i) {
+      const double lik = L[tri(i, k)];
+#pragma unroll
+      for (int j = k + 1; j <= i; ++j) S[tri(i, j)] -= lik * b[j] + L[tri(j, k)] * b[i];
+      S[tri(i, k)] = b[i] - 0.5 * lik * tkk;
+    }
+    ODEF_SCHED_FENCE();
+  });
+  // backward: elementary congruences with L_k^-T (only row/column k changes)
+  static_for<0, D>([&](auto kc) {
+    constexpr int k = D - 1 - decltype(kc)::value;
+    const double lkk = L[tri(k, k)];
+    const double inv = (lkk != 0.0) ? 1.0 / lkk : 0.0;
+    double t[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      double s = S[symidx(k, j)];
+#pragma unroll
+      for (int i = k + 1; i < D; ++i) s -= L[tri(i, k)] * S[symidx(i, j)];
+      t[j] = s;
+    }
+    double tk = t[k];
+#pragma unroll
+    for (int i = k + 1; i < D; ++i) tk -= L[tri(i, k)] * t[i];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+      if (j != k) S[symidx(k, j)] = t[j] * inv;
+    S[tri(k, k)] = tk * inv * inv;
+    ODEF_SCHED_FENCE();
+  });
+}
+
+// X <- A' X A in place on packed symmetric storage (A = At (x) I_d): A' = E'_1 ... E'_{NB-1} with
+// E'_J = I + sum_{j<J} At[j][J] e_J e_j' (block row J picks up the still-untouched block rows j < J).
+template <int d, int NB>
+__device__ inline void congruence_At_inplace(const PriorConsts& pc, double (&X)[d * NB * (d * NB + 1) / 2]) {
+  constexpr int D = d * NB;
+#pragma unroll
+  for (int J = NB - 1; J >= 1; --J) {
+    double Wd[d][d];
+#pragma unroll
+    for (int a = 0; a < d; ++a)
+#pragma unroll
+      for (int b = 0; b < d; ++b) {
+        double t = X[symidx(J * d + a, J * d + b)];
+#pragma unroll
+        for (int j = 0; j < J; ++j) t += pc.At[j][J] * X[symidx(j * d + a, J * d + b)];
+        Wd[a][b] = t;
+      }
+#pragma unroll
+    for (int a = 0; a < d; ++a)
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        if (c / d == J) continue;
+        double t = X[symidx(J * d + a, c)];
+#pragma unroll
+        for (int j = 0; j < J; ++j) t += pc.At[j][J] * X[symidx(j * d + a, c)];
+        X[symidx(J * d + a, c)] = t;
+      }
+#pragma unroll
+    for (int a = 0; a < d; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) {
+        double t = Wd[a][b];
+#pragma unroll
+        for (int j = 0; j < J; ++j) t += pc.At[j][J] * X[symidx(J * d + a, j * d + b)];
+        X[tri(J * d + a, J * d + b)] = t;
+      }
+  }
+}
+
+template <int d, int q>
+__device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned lane, const LaneMem& xl) {
+  constexpr int NB = q + 1, D = d * NB, TRI = D * (D + 1) / 2;
+  const long i = i0 + lane;
+  const long n = P.adaptive ? (long)P.nsaved[i] : P.n_save;
+  const size_t N = (size_t)P.N;
+  const PriorConsts& pc = P.pc;
+  // The smoothed covariance of time i+1 is NOT carried in registers: it is re-read from the record
+  // written one iteration earlier (L2-resident), which keeps the live set at two packed matrices.
+  double ms[D];
+  for (int w = 0; w < 2; ++w) {  // first and last record are copied (src/smoothing.jl:11)
+    const long s = w == 0 ? 0 : n - 1;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      ms[k] = P.mean[((size_t)s * D + k) * N + i];
+      P.smean[((size_t)s * D + k) * N + i] = ms[k];
+    }
+#pragma unroll
+    for (int k = 0; k < TRI; ++k) P.scov[((size_t)s * TRI + k) * N + i] = P.cov[((size_t)s * TRI + k) * N + i];
+  }
+  bool nan_seen = false;
+  for (long s = n - 2; s >= 1; --s) {
+    double h, pj[NB], pij[NB];
+    if (P.adaptive) {
+      h = P.tsave[(size_t)(s + 1) * N + i] - P.tsave[(size_t)s * N + i];
+      double val = (h != 0.0) ? precond_val<q>(h) : 1.0;
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        pj[J] = val;
+        pij[J] = 1.0 / val;
+        val *= h;
+      }
+    } else {
+      h = P.hs[s];
+      const double* __restrict__ tab = P.ptab + (size_t)P.tab_idx[s] * kTabStride;
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        pj[J] = tab[kTabPJ + J];
+        pij[J] = tab[kTabPIJ + J];
+      }
+    }
+    if (h == 0.0) {  // src/smoothing.jl:13-16
+#pragma unroll
+      for (int k = 0; k < D; ++k) P.smean[((size_t)s * D + k) * N + i] = ms[k];
+#pragma unroll
+      for (int k = 0; k < TRI; ++k) P.scov[((size_t)s * TRI + k) * N + i] = P.scov[((size_t)(s + 1) * TRI + k) * N + i];
+      continue;
+    }
+    const double sigma2 = P.diff[(size_t)(s + 1) * N + i];
+    // x_i and x_{i+1}^s in preconditioned coordinates (src/smoothing.jl:23-24)
+    double mt[D], B[TRI], Cs[TRI];
+#pragma unroll
+    for (int k = 0; k < D; ++k) mt[k] = pj[k / d] * P.mean[((size_t)s * D + k) * N + i];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b <= a; ++b) {
+        const double pp = pj[a / d] * pj[b / d];
+        const double x = P.cov[((size_t)s * TRI + tri(a, b)) * N + i] * pp;
+        xl.set(tri(a, b), x);
+        B[tri(a, b)] = x;
+        Cs[tri(a, b)] = P.scov[((size_t)(s + 1) * TRI + tri(a, b)) * N + i] * pp;
+      }
+    // predict (src/smoothing.jl:38)
+    double dl[D];
+#pragma unroll
+    for (int J = 0; J < NB; ++J)
+#pragma unroll
+      for (int a = 0; a < d; ++a) {
+        double t = mt[J * d + a];
+#pragma unroll
+        for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * mt[j * d + a];
+        dl[J * d + a] = pj[J] * ms[J * d + a] - t;  // m^s_+ - m^-
+      }
+    ODEF_SCHED_FENCE();
+    predict_cov_inplace<d, NB>(pc, B, sigma2);
+    ODEF_SCHED_FENCE();
+#pragma unroll
+    for (int k = 0; k < TRI; ++k) Cs[k] -= B[k];  // M = S^s_+ - S^-
+    int fixes = 0;
+    chol_packed<D>(B, fixes);
+    ODEF_SCHED_FENCE();
+    // w = A' B^-1 delta ;  m^s = m + X w  (src/smoothing.jl:42-44)
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      double t = dl[k];
+#pragma unroll
+      for (int c = 0; c < k; ++c) t -= B[tri(k, c)] * dl[c];
+      dl[k] = (B[tri(k, k)] != 0.0) ? t / B[tri(k, k)] : 0.0;
+    }
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+      double t = dl[k];
+#pragma unroll
+      for (int c = k + 1; c < D; ++c) t -= B[tri(c, k)] * dl[c];
+      dl[k] = (B[tri(k, k)] != 0.0) ? t / B[tri(k, k)] : 0.0;
+    }
+    double wv[D];
+#pragma unroll
+    for (int K = 0; K < NB; ++K)
+#pragma unroll
+      for (int b = 0; b < d; ++b) {
+        double t = dl[K * d + b];
+#pragma unroll
+        for (int j = 0; j < K; ++j) t += pc.At[j][K] * dl[j * d + b];
+        wv[K * d + b] = t;
+      }
+    // Z = B^-1 M B^-1 ;  W = A' Z A
+    ODEF_SCHED_FENCE();
+    two_sided_inverse<D>(Cs, B);
+    ODEF_SCHED_FENCE();
+    congruence_At_inplace<d, NB>(pc, Cs);
+    ODEF_SCHED_FENCE();
+    // rows of the result, stored as they are produced
+    static_for<0, D>([&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      double xa[D], u[D];
+#pragma unroll
+      for (int c = 0; c < D; ++c) xa[c] = xl.get(symidx(a, c));
+      double mnew = mt[a];
+#pragma unroll
+      for (int c = 0; c < D; ++c) mnew += xa[c] * wv[c];
+      ms[a] = mnew * pij[a / d];  // un-precondition (src/smoothing.jl:26)
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t += xa[k] * Cs[symidx(k, c)];
+        u[c] = t;
+      }
+#pragma unroll
+      for (int b = 0; b <= a; ++b) {
+        double t = xa[b];
+#pragma unroll
+        for (int k = 0; k < D; ++k) t += u[k] * xl.get(symidx(k, b));
+        P.scov[((size_t)s * TRI + tri(a, b)) * N + i] = t * (pij[a / d] * pij[b / d]);
+      }
+      ODEF_SCHED_FENCE();
+    });
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      nan_seen = nan_seen || !(ms[k] == ms[k]);
+      P.smean[((size_t)s * D + k) * N + i] = ms[k];
+    }
+  }
+  if (nan_seen) P.retcode[i] = 3;  // "NaNs after smoothing" (src/smoothing.jl:25)
+}
+
+}  // namespace odef

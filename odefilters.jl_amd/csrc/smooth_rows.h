@@ -45,14 +45,6 @@ struct RowState {
   double atr[MAXNB], qtr[MAXNB];  // row (r / d) of At and Qt: lane constants
 };
 
-// keeps the instruction scheduler from hoisting every LDS read of an unrolled loop nest to the top
-// (which costs > 350 registers and leaves one wave per SIMD)
-#ifdef ODEF_HOST_EMUL
-#define ODEF_SCHED_FENCE()
-#else
-#define ODEF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
-
 #ifdef ODEF_HOST_EMUL
 #define ODEF_ROWS_PHASE(...)                                   \
   for (int lane_ = 0; lane_ < TEAM; ++lane_) {                 \

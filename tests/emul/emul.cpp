@@ -6,6 +6,7 @@
 #include "../../odefilters.jl_amd/csrc/dispatch.h"
 #include "../../odefilters.jl_amd/csrc/smooth_team.h"
 #include "../../odefilters.jl_amd/csrc/smooth_rows.h"
+#include "../../odefilters.jl_amd/csrc/smooth_lane.h"
 #include "../../odefilters.jl_amd/csrc/filter_team.h"
 #include <vector>
 #include <cstring>
@@ -63,7 +64,11 @@ struct RunSmooth {
   const SmoothParams& P;
   template <int d, int q>
   void operator()() {
-    if constexpr (d * (q + 1) <= 32) {  // row-per-lane teams: all lanes of a team emulated phase by phase
+    if constexpr (d * (q + 1) <= 12) {  // lane-per-trajectory smoother, lane-private memory = a plain array here
+      constexpr int D = d * (q + 1);
+      std::vector<double> x(D * (D + 1) / 2);
+      for (long i = 0; i < P.N; ++i) smooth_lane_v2<d, q>(P, i, 0, LaneMem{x.data(), 1});
+    } else if constexpr (d * (q + 1) <= 32) {  // row-per-lane teams: all lanes of a team emulated phase by phase
       constexpr int D = d * (q + 1), TEAM = (D <= 16) ? 16 : 32;
       std::vector<double> ws(RowsWs<d, q + 1>::size);
       std::vector<RowState<D>> st(TEAM);

@@ -113,3 +113,14 @@ def test_pleiades_team_filter(q, ek1):
     assert r["retcode"][0] == 0
     if q < 5:  # at order 5 the residual of the first steps is pure rounding noise in BOTH implementations
         assert P.cov_err(r["cov"][0], sol.covs(smoothed=False)) < 1e-6
+
+
+@pytest.mark.parametrize("q", [4, 5])
+def test_rows_smoother_larger_state(q):
+    """D = 15 / 18 (Lorenz, order 4 / 5): the row-per-lane team smoother (smooth_rows.h, 16- and 32-lane teams)."""
+    vf = orc.vector_field("lorenz63")
+    alg = orc.EK1(order=q)
+    kw = dict(tspan=(0.0, 0.125), dt=2.0**-8)
+    base, nm, nc = P.oracle_noise(vf, alg, vf.u0, kw, True)
+    r = E.emul_solve(vf.rhs_id, 3, q, True, vf.u0[None, :], vf.p, tgrid=np.array(base.t), smooth=True)
+    P.check_against_oracle(r["smean"][0], r["scov"][0], base.means(smoothed=True), base.covs(smoothed=True), 3, nm, nc, f"rows q={q}")
