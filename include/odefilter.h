@@ -22,6 +22,7 @@
  *                                   + PI controller (exponents src/alg_utils.jl:23-24; loop is OrdinaryDiffEq's)
  *   odef_smooth                     postamble! -> smooth_all! -> smooth!         src/integrator_utils.jl:2-30,
  *                                                                                src/smoothing.jl:4-63
+ *   odef_dense_output               sol(t), GaussianODEFilterPosterior            src/solution.jl:165-214
  *   odef_get / odef_get_device      sol.t, sol.x_filt, sol.x_smooth, sol.diffusions, sol.log_likelihood,
  *                                   sol.destats, sol.retcode                     src/solution.jl:8-24
  *   odef_predict / odef_update /
@@ -96,6 +97,8 @@ typedef enum {
   ODEF_F_SMOOTH_MEAN = 11,
   ODEF_F_SMOOTH_COV_TRIL = 12,
   ODEF_F_U0 = 13,              /* [d][N] initial values as held on the device */
+  ODEF_F_DENSE_MEAN = 14,      /* [n_q][D][N]   result of odef_dense_output */
+  ODEF_F_DENSE_COV_TRIL = 15,  /* [n_q][TRI][N] */
   ODEF_F_COUNT_
 } odef_field;
 
@@ -151,6 +154,11 @@ int odef_solve_adaptive(odef_ctx* ctx, double t1, double abstol, double reltol, 
                         const odef_controller* ctrl, int64_t max_steps);
 /* Rauch-Tung-Striebel pass over the stored filter states. */
 int odef_smooth(odef_ctx* ctx);
+
+/* Dense output / saveat (src/solution.jl:165-210): posterior of every trajectory at the n_q host times tq
+ * (smoothed != 0: the smoothed posterior, needs odef_smooth first).  Results in ODEF_F_DENSE_MEAN /
+ * ODEF_F_DENSE_COV_TRIL.  Times before t0 give NaN records (the reference throws).  State dimension <= 12. */
+int odef_dense_output(odef_ctx* ctx, const double* tq, int64_t n_q, int smoothed);
 
 int64_t odef_n_save(const odef_ctx* ctx); /* leading dimension of MEAN/COV_TRIL/DIFFUSION/T */
 int odef_field_bytes(const odef_ctx* ctx, int field, size_t* bytes);

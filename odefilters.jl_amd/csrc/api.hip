@@ -49,6 +49,11 @@ struct odef_ctx {
   // time grid of the last fixed solve
   std::vector<double> tgrid;
   double* d_hs = nullptr;
+  double* d_tgrid = nullptr;
+  double* d_tq = nullptr;
+  size_t tq_cap = 0;
+  long n_q = 0;
+  bool smoothed_done = false;
   double* d_ptab = nullptr;
   int* d_tab_idx = nullptr;
   size_t grid_cap = 0;
@@ -136,6 +141,8 @@ size_t field_count(const odef_ctx* c, int field, long n_save) {
     case ODEF_F_DIFFUSION: return (size_t)n_save * N;
     case ODEF_F_T: return c->adaptive ? (size_t)n_save * N : (size_t)n_save;
     case ODEF_F_U0: return (size_t)c->d * N;
+    case ODEF_F_DENSE_MEAN: return (size_t)c->n_q * c->D * N;
+    case ODEF_F_DENSE_COV_TRIL: return (size_t)c->n_q * c->TRI * N;
     default: return N;
   }
 }
@@ -291,6 +298,8 @@ void odef_destroy(odef_ctx* c) {
   if (c->d_ws) (void)hipFree(c->d_ws);
   if (c->d_hs) (void)hipFree(c->d_hs);
   if (c->d_ptab) (void)hipFree(c->d_ptab);
+  if (c->d_tgrid) (void)hipFree(c->d_tgrid);
+  if (c->d_tq) (void)hipFree(c->d_tq);
   if (c->d_tab_idx) (void)hipFree(c->d_tab_idx);
   for (int k = 0; k < 4; ++k)
     if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
@@ -418,6 +427,7 @@ static int finish_filter(odef_ctx* c, int nlaunch) {
   HIPCHK(c, hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]));
   c->nl[0] = nlaunch;
   c->solved = true;
+  c->smoothed_done = false;
   return 0;
 }
 
@@ -460,18 +470,20 @@ int odef_solve_fixed(odef_ctx* c, const double* tgrid, int64_t n_t) {
     idx[n] = k;
   }
   if (c->grid_cap < (size_t)n_t) {
-    if (c->d_hs) { HIPCHK(c, hipFree(c->d_hs)); HIPCHK(c, hipFree(c->d_ptab)); HIPCHK(c, hipFree(c->d_tab_idx)); }
-    c->d_hs = c->d_ptab = nullptr;
+    if (c->d_hs) { HIPCHK(c, hipFree(c->d_hs)); HIPCHK(c, hipFree(c->d_ptab)); HIPCHK(c, hipFree(c->d_tab_idx)); HIPCHK(c, hipFree(c->d_tgrid)); }
+    c->d_hs = c->d_ptab = c->d_tgrid = nullptr;
     c->d_tab_idx = nullptr;
     c->grid_cap = 0;
     HIPCHK(c, hipMalloc((void**)&c->d_hs, sizeof(double) * n_t));
     HIPCHK(c, hipMalloc((void**)&c->d_ptab, sizeof(double) * n_t * kTabStride));  // worst case: all h distinct
     HIPCHK(c, hipMalloc((void**)&c->d_tab_idx, sizeof(int) * n_t));
+    HIPCHK(c, hipMalloc((void**)&c->d_tgrid, sizeof(double) * n_t));
     c->grid_cap = (size_t)n_t;
   }
   HIPCHK(c, hipMemcpyAsync(c->d_hs, hs.data(), sizeof(double) * nsteps, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_ptab, tabs.data(), sizeof(double) * tabs.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_tab_idx, idx.data(), sizeof(int) * nsteps, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_tgrid, tgrid, sizeof(double) * n_t, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));  // the host vectors are locals
   if (alloc_outputs(c, c->n_save)) return -1;
   FilterParams P;
@@ -571,6 +583,53 @@ int odef_smooth(odef_ctx* c) {
   HIPCHK(c, hipEventSynchronize(c->ev[3]));
   HIPCHK(c, hipEventElapsedTime(&c->ms[1], c->ev[2], c->ev[3]));
   c->nl[1] = 1;
+  c->smoothed_done = true;
+  return 0;
+}
+
+int odef_dense_output(odef_ctx* c, const double* tq, int64_t n_q, int smoothed) {
+  if (!c || !tq) return fail(c, "odef_dense_output: null argument");
+  if (!c->solved) return fail(c, "odef_dense_output: call odef_solve_* first");
+  if (c->cfg.save_mode != ODEF_SAVE_EVERYSTEP) return fail(c, "odef_dense_output: needs ODEF_SAVE_EVERYSTEP");
+  if (smoothed && !c->smoothed_done) return fail(c, "odef_dense_output: smoothed posterior requested but odef_smooth has not run");
+  if (n_q < 1 || n_q > 65535) return fail(c, "odef_dense_output: n_q must be in 1..65535");
+  if (c->team_path || c->D > 12) return fail(c, "odef_dense_output: built for state dimension <= 12 (got %d)", c->D);
+  if (set_device(c)) return -1;
+  if (c->tq_cap < (size_t)n_q) {
+    if (c->d_tq) HIPCHK(c, hipFree(c->d_tq));
+    c->d_tq = nullptr;
+    HIPCHK(c, hipMalloc((void**)&c->d_tq, sizeof(double) * n_q));
+    c->tq_cap = (size_t)n_q;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_tq, tq, sizeof(double) * n_q, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->n_q = (long)n_q;
+  const size_t N = (size_t)c->cfg.n_traj;
+  if (ensure(c, ODEF_F_DENSE_MEAN, (size_t)n_q * c->D * N * sizeof(double))) return -1;
+  if (ensure(c, ODEF_F_DENSE_COV_TRIL, (size_t)n_q * c->TRI * N * sizeof(double))) return -1;
+  DenseParams P;
+  std::memset(&P, 0, sizeof P);
+  P.pc = c->pc;
+  P.N = c->cfg.n_traj;
+  P.n_save = c->n_save;
+  P.adaptive = c->adaptive;
+  P.smoothed = smoothed != 0;
+  P.tgrid = c->d_tgrid;
+  P.tsave = (const double*)c->f[ODEF_F_T].ptr;
+  P.nsaved = (const int*)c->f[ODEF_F_NSAVED].ptr;
+  P.mean = (const double*)c->f[ODEF_F_MEAN].ptr;
+  P.cov = (const double*)c->f[ODEF_F_COV_TRIL].ptr;
+  P.diff = (const double*)c->f[ODEF_F_DIFFUSION].ptr;
+  P.smean = (const double*)c->f[ODEF_F_SMOOTH_MEAN].ptr;
+  P.scov = (const double*)c->f[ODEF_F_SMOOTH_COV_TRIL].ptr;
+  P.tq = c->d_tq;
+  P.n_q = (long)n_q;
+  P.qmean = (double*)c->f[ODEF_F_DENSE_MEAN].ptr;
+  P.qcov = (double*)c->f[ODEF_F_DENSE_COV_TRIL].ptr;
+  const int rc = c->d == 2 ? launch_dense_d2(c->q, P, c->stream) : c->d == 3 ? launch_dense_d3(c->q, P, c->stream) : -3;
+  if (rc) return fail(c, "odef_dense_output: no kernel for d %d order %d", c->d, c->q);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
 

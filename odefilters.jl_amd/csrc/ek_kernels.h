@@ -7,6 +7,7 @@
 #include "smooth_team.h"
 #include "smooth_rows.h"
 #include "smooth_lane.h"
+#include "dense_lane.h"
 #include "filter_team.h"
 #include "launch.h"
 
@@ -56,6 +57,30 @@ __global__ __launch_bounds__(kWave) void rts_smooth_lane_kernel(const SmoothPara
   const LaneMem xl{lds + threadIdx.x, kWave};
   if (i0 + threadIdx.x < P.N) smooth_lane_v2<d, q>(P, i0, threadIdx.x, xl);
 }
+
+// Dense output: blockIdx.y = query time, one lane per trajectory (D <= 12).
+template <int d, int q>
+__global__ __launch_bounds__(kWave) void dense_output_kernel(const DenseParams P) {
+  constexpr int D = d * (q + 1), TRI = D * (D + 1) / 2;
+  __shared__ double lds[TRI * kWave];
+  const long i = (long)blockIdx.x * kWave + threadIdx.x;
+  const LaneMem xl{lds + threadIdx.x, kWave};
+  if (i < P.N) dense_lane<d, q>(P, i, (long)blockIdx.y, xl);
+}
+struct LaunchDense {
+  const DenseParams& P;
+  hipStream_t s;
+  int rc = 0;
+  template <int d, int q>
+  void operator()() {
+    if constexpr (d * (q + 1) <= kSmoothLaneMaxD) {
+      dim3 grid((unsigned)((P.N + kWave - 1) / kWave), (unsigned)P.n_q);
+      hipLaunchKernelGGL((dense_output_kernel<d, q>), grid, dim3(kWave), 0, s, P);
+    } else {
+      rc = -3;
+    }
+  }
+};
 
 // Workgroup-per-trajectory kernels (large state dimension): 256 threads cooperate on one trajectory,
 // matrices in a per-trajectory global workspace.

@@ -4,4 +4,9 @@ int launch_smooth_d2(int q, const SmoothParams& P, hipStream_t s) {
   LaunchSmooth f{P, s};
   return dispatch_smooth_order<2>(q, f);
 }
+int launch_dense_d2(int q, const DenseParams& P, hipStream_t s) {
+  LaunchDense f{P, s};
+  const int rc = dispatch_smooth_order<2>(q, f);
+  return rc ? rc : f.rc;
+}
 }  // namespace odef

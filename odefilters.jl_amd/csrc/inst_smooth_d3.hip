@@ -4,4 +4,9 @@ int launch_smooth_d3(int q, const SmoothParams& P, hipStream_t s) {
   LaunchSmooth f{P, s};
   return dispatch_smooth_order<3>(q, f);
 }
+int launch_dense_d3(int q, const DenseParams& P, hipStream_t s) {
+  LaunchDense f{P, s};
+  const int rc = dispatch_smooth_order<3>(q, f);
+  return rc ? rc : f.rc;
+}
 }  // namespace odef

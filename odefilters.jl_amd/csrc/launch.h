@@ -4,6 +4,7 @@
 #include "ek_lane.h"
 #include "filter_team.h"
 #include "team.h"
+#include "dense_lane.h"
 
 namespace odef {
 // returns 0, or -2 when (rhs, q) is not instantiated
@@ -17,6 +18,9 @@ int launch_filter_vanderpol(int q, int ek1, int adaptive, const FilterParams& P,
 int launch_filter_linear(int q, int ek1, int adaptive, const FilterParams& P, hipStream_t s);
 int launch_smooth_d2(int q, const SmoothParams& P, hipStream_t s);
 int launch_smooth_d3(int q, const SmoothParams& P, hipStream_t s);
+// returns -3 when the state dimension is outside the dense-output kernel's range (D <= 12)
+int launch_dense_d2(int q, const DenseParams& P, hipStream_t s);
+int launch_dense_d3(int q, const DenseParams& P, hipStream_t s);
 // workgroup-per-trajectory path (Pleiades, d = 28)
 int launch_filter_pleiades(int q, int ek1, const TeamFilterParams& TP, hipStream_t s);
 int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s);

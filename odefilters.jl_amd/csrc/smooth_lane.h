@@ -115,6 +115,95 @@ __device__ inline void congruence_At_inplace(const PriorConsts& pc, double (&X)[
   }
 }
 
+// Core of one RTS step for one trajectory in preconditioned coordinates (src/smoothing.jl:31-63).
+//   in : mt = P m (filter mean), B = P S P (filter covariance, packed; destroyed), xl holds the same P S P,
+//        msn = P m^s_+, Cs = P S^s_+ P (packed; destroyed), sigma2, pij = diag of P^-1 per derivative block
+//   out: ms_out (un-preconditioned smoothed mean), sink(k, v) for every packed entry k of the
+//        un-preconditioned smoothed covariance, in storage order
+template <int d, int NB, class CovSink>
+__device__ inline void rts_step_core(const PriorConsts& pc, const double (&pij)[NB], const double (&mt)[d * NB],
+                                     double (&B)[d * NB * (d * NB + 1) / 2], double (&Cs)[d * NB * (d * NB + 1) / 2],
+                                     const double (&msn)[d * NB], double sigma2, const LaneMem& xl,
+                                     double (&ms_out)[d * NB], CovSink& sink) {
+  constexpr int D = d * NB, TRI = D * (D + 1) / 2;
+  // predict (src/smoothing.jl:38)
+  double dl[D];
+#pragma unroll
+  for (int J = 0; J < NB; ++J)
+#pragma unroll
+    for (int a = 0; a < d; ++a) {
+      double t = mt[J * d + a];
+#pragma unroll
+      for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * mt[j * d + a];
+      dl[J * d + a] = msn[J * d + a] - t;  // m^s_+ - m^-
+    }
+  ODEF_SCHED_FENCE();
+  predict_cov_inplace<d, NB>(pc, B, sigma2);
+  ODEF_SCHED_FENCE();
+#pragma unroll
+  for (int k = 0; k < TRI; ++k) Cs[k] -= B[k];  // M = S^s_+ - S^-
+  int fixes = 0;
+  chol_packed<D>(B, fixes);
+  ODEF_SCHED_FENCE();
+  // w = A' B^-1 delta ;  m^s = m + X w  (src/smoothing.jl:42-44)
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    double t = dl[k];
+#pragma unroll
+    for (int c = 0; c < k; ++c) t -= B[tri(k, c)] * dl[c];
+    dl[k] = (B[tri(k, k)] != 0.0) ? t / B[tri(k, k)] : 0.0;
+  }
+#pragma unroll
+  for (int k = D - 1; k >= 0; --k) {
+    double t = dl[k];
+#pragma unroll
+    for (int c = k + 1; c < D; ++c) t -= B[tri(c, k)] * dl[c];
+    dl[k] = (B[tri(k, k)] != 0.0) ? t / B[tri(k, k)] : 0.0;
+  }
+  double wv[D];
+#pragma unroll
+  for (int K = 0; K < NB; ++K)
+#pragma unroll
+    for (int b = 0; b < d; ++b) {
+      double t = dl[K * d + b];
+#pragma unroll
+      for (int j = 0; j < K; ++j) t += pc.At[j][K] * dl[j * d + b];
+      wv[K * d + b] = t;
+    }
+  // Z = B^-1 M B^-1 ;  W = A' Z A
+  ODEF_SCHED_FENCE();
+  two_sided_inverse<D>(Cs, B);
+  ODEF_SCHED_FENCE();
+  congruence_At_inplace<d, NB>(pc, Cs);
+  ODEF_SCHED_FENCE();
+  // rows of the result, handed out as they are produced
+  static_for<0, D>([&](auto ac) {
+    constexpr int a = decltype(ac)::value;
+    double xa[D], u[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) xa[c] = xl.get(symidx(a, c));
+    double mnew = mt[a];
+#pragma unroll
+    for (int c = 0; c < D; ++c) mnew += xa[c] * wv[c];
+    ms_out[a] = mnew * pij[a / d];  // un-precondition (src/smoothing.jl:26)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) t += xa[k] * Cs[symidx(k, c)];
+      u[c] = t;
+    }
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      double t = xa[b];
+#pragma unroll
+      for (int k = 0; k < D; ++k) t += u[k] * xl.get(symidx(k, b));
+      sink(tri(a, b), t * (pij[a / d] * pij[b / d]));
+    }
+    ODEF_SCHED_FENCE();
+  });
+}
+
 template <int d, int q>
 __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned lane, const LaneMem& xl) {
   constexpr int NB = q + 1, D = d * NB, TRI = D * (D + 1) / 2;
@@ -178,82 +267,13 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
         B[tri(a, b)] = x;
         Cs[tri(a, b)] = P.scov[((size_t)(s + 1) * TRI + tri(a, b)) * N + i] * pp;
       }
-    // predict (src/smoothing.jl:38)
-    double dl[D];
+    double msn[D], msnew[D];
 #pragma unroll
-    for (int J = 0; J < NB; ++J)
+    for (int k = 0; k < D; ++k) msn[k] = pj[k / d] * ms[k];
+    auto sink = [&](int k, double v) { P.scov[((size_t)s * TRI + k) * N + i] = v; };
+    rts_step_core<d, NB>(pc, pij, mt, B, Cs, msn, sigma2, xl, msnew, sink);
 #pragma unroll
-      for (int a = 0; a < d; ++a) {
-        double t = mt[J * d + a];
-#pragma unroll
-        for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * mt[j * d + a];
-        dl[J * d + a] = pj[J] * ms[J * d + a] - t;  // m^s_+ - m^-
-      }
-    ODEF_SCHED_FENCE();
-    predict_cov_inplace<d, NB>(pc, B, sigma2);
-    ODEF_SCHED_FENCE();
-#pragma unroll
-    for (int k = 0; k < TRI; ++k) Cs[k] -= B[k];  // M = S^s_+ - S^-
-    int fixes = 0;
-    chol_packed<D>(B, fixes);
-    ODEF_SCHED_FENCE();
-    // w = A' B^-1 delta ;  m^s = m + X w  (src/smoothing.jl:42-44)
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      double t = dl[k];
-#pragma unroll
-      for (int c = 0; c < k; ++c) t -= B[tri(k, c)] * dl[c];
-      dl[k] = (B[tri(k, k)] != 0.0) ? t / B[tri(k, k)] : 0.0;
-    }
-#pragma unroll
-    for (int k = D - 1; k >= 0; --k) {
-      double t = dl[k];
-#pragma unroll
-      for (int c = k + 1; c < D; ++c) t -= B[tri(c, k)] * dl[c];
-      dl[k] = (B[tri(k, k)] != 0.0) ? t / B[tri(k, k)] : 0.0;
-    }
-    double wv[D];
-#pragma unroll
-    for (int K = 0; K < NB; ++K)
-#pragma unroll
-      for (int b = 0; b < d; ++b) {
-        double t = dl[K * d + b];
-#pragma unroll
-        for (int j = 0; j < K; ++j) t += pc.At[j][K] * dl[j * d + b];
-        wv[K * d + b] = t;
-      }
-    // Z = B^-1 M B^-1 ;  W = A' Z A
-    ODEF_SCHED_FENCE();
-    two_sided_inverse<D>(Cs, B);
-    ODEF_SCHED_FENCE();
-    congruence_At_inplace<d, NB>(pc, Cs);
-    ODEF_SCHED_FENCE();
-    // rows of the result, stored as they are produced
-    static_for<0, D>([&](auto ac) {
-      constexpr int a = decltype(ac)::value;
-      double xa[D], u[D];
-#pragma unroll
-      for (int c = 0; c < D; ++c) xa[c] = xl.get(symidx(a, c));
-      double mnew = mt[a];
-#pragma unroll
-      for (int c = 0; c < D; ++c) mnew += xa[c] * wv[c];
-      ms[a] = mnew * pij[a / d];  // un-precondition (src/smoothing.jl:26)
-#pragma unroll
-      for (int c = 0; c < D; ++c) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) t += xa[k] * Cs[symidx(k, c)];
-        u[c] = t;
-      }
-#pragma unroll
-      for (int b = 0; b <= a; ++b) {
-        double t = xa[b];
-#pragma unroll
-        for (int k = 0; k < D; ++k) t += u[k] * xl.get(symidx(k, b));
-        P.scov[((size_t)s * TRI + tri(a, b)) * N + i] = t * (pij[a / d] * pij[b / d]);
-      }
-      ODEF_SCHED_FENCE();
-    });
+    for (int k = 0; k < D; ++k) ms[k] = msnew[k];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
       nan_seen = nan_seen || !(ms[k] == ms[k]);

@@ -30,7 +30,7 @@ RHS_DIMS = {"fhn": (2, 3), "lorenz63": (3, 3), "lotka_volterra": (2, 4), "vander
 SAVE_FINAL, SAVE_EVERYSTEP = 0, 1
 RETCODES = {0: "Success", 1: "MaxIters", 2: "DtLessThanMin", 3: "Unstable", 4: "Unstable"}
 (F_MEAN, F_COV_TRIL, F_DIFFUSION, F_T, F_LOGLIK, F_NACCEPT, F_NREJECT, F_NF, F_NJAC, F_NSAVED, F_RETCODE,
- F_SMOOTH_MEAN, F_SMOOTH_COV_TRIL, F_U0) = range(14)
+ F_SMOOTH_MEAN, F_SMOOTH_COV_TRIL, F_U0, F_DENSE_MEAN, F_DENSE_COV_TRIL) = range(16)
 _INT_FIELDS = {F_NACCEPT, F_NREJECT, F_NF, F_NJAC, F_NSAVED, F_RETCODE}
 MAX_ORDER = 5
 
@@ -64,6 +64,7 @@ SYMBOLS = {
     "odef_solve_fixed": (C.c_int, [_vp, _dp, C.c_int64]),
     "odef_solve_adaptive": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(OdefController), C.c_int64]),
     "odef_smooth": (C.c_int, [_vp]),
+    "odef_dense_output": (C.c_int, [_vp, _dp, C.c_int64, C.c_int]),
     "odef_n_save": (C.c_int64, [_vp]),
     "odef_field_bytes": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_size_t)]),
     "odef_get": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
@@ -191,6 +192,18 @@ class Context:
 
     def smooth(self):
         self._chk(self.lib.odef_smooth(self._h))
+
+    def dense_output(self, tq, smoothed: bool):
+        """Posterior at the times `tq` for every trajectory: (mean [n_q, D, N], cov_tril [n_q, TRI, N])."""
+        tq = np.ascontiguousarray(tq, dtype=np.float64)
+        self._chk(self.lib.odef_dense_output(self._h, _as_dp(tq), len(tq), int(smoothed)))
+        nb = self.field_bytes(F_DENSE_MEAN)
+        m = np.empty(nb // 8)
+        self._chk(self.lib.odef_get(self._h, F_DENSE_MEAN, m.ctypes.data_as(_vp), nb))
+        nb = self.field_bytes(F_DENSE_COV_TRIL)
+        c = np.empty(nb // 8)
+        self._chk(self.lib.odef_get(self._h, F_DENSE_COV_TRIL, c.ctypes.data_as(_vp), nb))
+        return m.reshape(len(tq), self.D, self.N), c.reshape(len(tq), self.TRI, self.N)
 
     def synchronize(self):
         self._chk(self.lib.odef_synchronize(self._h))
@@ -450,6 +463,14 @@ class EnsembleSolution:
         """Covariance of sol.pu = SolProj * x (src/integrator_utils.jl:21,45)."""
         c = self.x_smooth_cov() if self.smoothed else self.x_filt_cov()
         return c[:, :, : self.d, : self.d]
+
+    def __call__(self, t, smoothed: Optional[bool] = None):
+        """`sol(t)`: dense output (src/solution.jl:211-215).  Returns (mean [N, n_t, D], cov [N, n_t, D, D]) of the
+        posterior at the times `t` (smoothed when the solution is, as the reference's interpolant)."""
+        tq = np.atleast_1d(np.asarray(t, float))
+        sm = self.smoothed if smoothed is None else smoothed
+        m, c = self.ctx.dense_output(tq, sm)
+        return m.transpose(2, 0, 1), unpack_tril(c.transpose(2, 0, 1), self.D)
 
     @property
     def diffusions(self) -> np.ndarray:

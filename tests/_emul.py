@@ -21,7 +21,7 @@ def build():
     src = os.path.join(HERE, "emul", "emul.cpp")
     out = os.path.join(HERE, "emul", "libodef_emul.so")
     deps = [src] + [os.path.join(ROOT, "odefilters.jl_amd", "csrc", f) for f in
-                    ("ek_math.h", "ek_lane.h", "rhs.h", "dispatch.h", "odef_platform.h", "team.h", "smooth_team.h", "filter_team.h", "smooth_rows.h", "smooth_lane.h")]
+                    ("ek_math.h", "ek_lane.h", "rhs.h", "dispatch.h", "odef_platform.h", "team.h", "smooth_team.h", "filter_team.h", "smooth_rows.h", "smooth_lane.h", "dense_lane.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++20", "-shared", "-fPIC", "-Wno-unknown-pragmas", src, "-o", out])
     return out
@@ -86,7 +86,7 @@ def unpack_tril(c, D):
 
 def emul_solve(rhs_id, d, q, ek1, u0s, p, *, team=False, tgrid=None, adaptive=False, t0=0.0, t1=1.0, abstol=1e-6, reltol=1e-3,
                dt0=1e-2, max_save=4096, everystep=True, fixed_diffusion=False, want_loglik=True, smooth=False,
-               ctrl=None):
+               ctrl=None, dense_t=None):
     """u0s [N, d]; p [np] shared.  Returns dict of numpy arrays in the device layout transposed
     to trajectory-major: mean [N, n_save, D], cov [N, n_save, D, D] ..."""
     u0s = np.asarray(u0s, float)
@@ -141,4 +141,16 @@ def emul_solve(rhs_id, d, q, ek1, u0s, p, *, team=False, tgrid=None, adaptive=Fa
         assert rc == 0, rc
         out["smean"] = smean.transpose(2, 0, 1)
         out["scov"] = unpack_tril(scov.transpose(2, 0, 1), D)
+    if dense_t is not None:
+        class EmulDense(C.Structure):
+            _fields_ = [("a", C.POINTER(EmulArgs)), ("smoothed", C.c_int), ("tq", dp), ("n_q", C.c_long), ("qmean", dp), ("qcov", dp)]
+        tq = np.ascontiguousarray(dense_t, float)
+        qm = np.zeros((len(tq), D, N)); qc = np.zeros((len(tq), TRI, N))
+        if not adaptive:
+            a.hs = _p(tg)  # emul_dense reads the fixed time grid from here
+        e = EmulDense(C.pointer(a), int(smooth), _p(tq), len(tq), _p(qm), _p(qc))
+        rc = lib().emul_dense(C.byref(e), d)
+        assert rc == 0, rc
+        out["qmean"] = qm.transpose(2, 0, 1)
+        out["qcov"] = unpack_tril(qc.transpose(2, 0, 1), D)
     return out

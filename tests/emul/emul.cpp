@@ -7,6 +7,7 @@
 #include "../../odefilters.jl_amd/csrc/smooth_team.h"
 #include "../../odefilters.jl_amd/csrc/smooth_rows.h"
 #include "../../odefilters.jl_amd/csrc/smooth_lane.h"
+#include "../../odefilters.jl_amd/csrc/dense_lane.h"
 #include "../../odefilters.jl_amd/csrc/filter_team.h"
 #include <vector>
 #include <cstring>
@@ -142,4 +143,41 @@ extern "C" int emul_filter_team(const EmulArgs* a) {
     case 5: return dispatch_order<RhsPleiades>(a->q, a->ek1, r);
     default: return -2;
   }
+}
+
+// dense output (dense_lane.h)
+struct EmulDense {
+  const EmulArgs* a;
+  int smoothed;
+  const double* tq;
+  long n_q;
+  double *qmean, *qcov;
+};
+struct RunDense {
+  const DenseParams& P;
+  template <int d, int q>
+  void operator()() {
+    if constexpr (d * (q + 1) <= 12) {
+      constexpr int D = d * (q + 1);
+      std::vector<double> x(D * (D + 1) / 2);
+      for (long j = 0; j < P.n_q; ++j)
+        for (long i = 0; i < P.N; ++i) dense_lane<d, q>(P, i, j, LaneMem{x.data(), 1});
+    }
+  }
+};
+extern "C" int emul_dense(const EmulDense* e, int d) {
+  const EmulArgs* a = e->a;
+  DenseParams P;
+  std::memset(&P, 0, sizeof P);
+  std::memcpy(P.pc.At, a->At, sizeof(P.pc.At));
+  std::memcpy(P.pc.Qt, a->Qt, sizeof(P.pc.Qt));
+  std::memcpy(P.pc.QLt, a->QLt, sizeof(P.pc.QLt));
+  P.N = a->N; P.n_save = a->n_save; P.adaptive = a->adaptive; P.smoothed = e->smoothed;
+  P.tgrid = a->hs;  /* the Python driver passes the time grid here for dense output */
+  P.tsave = a->tsave; P.nsaved = a->nsaved; P.mean = a->mean; P.cov = a->cov; P.diff = a->diff;
+  P.smean = a->smean; P.scov = a->scov; P.tq = e->tq; P.n_q = e->n_q; P.qmean = e->qmean; P.qcov = e->qcov;
+  RunDense r{P};
+  if (d == 2) return dispatch_smooth_order<2>(a->q, r);
+  if (d == 3) return dispatch_smooth_order<3>(a->q, r);
+  return -2;
 }

@@ -124,3 +124,28 @@ def test_rows_smoother_larger_state(q):
     base, nm, nc = P.oracle_noise(vf, alg, vf.u0, kw, True)
     r = E.emul_solve(vf.rhs_id, 3, q, True, vf.u0[None, :], vf.p, tgrid=np.array(base.t), smooth=True)
     P.check_against_oracle(r["smean"][0], r["scov"][0], base.means(smoothed=True), base.covs(smoothed=True), 3, nm, nc, f"rows q={q}")
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+@pytest.mark.parametrize("smoothed", [False, True])
+def test_dense_output(adaptive, smoothed):
+    """sol(t) (src/solution.jl:165-210): interior points, exact grid points, and beyond the last time."""
+    vf = orc.vector_field("lorenz63")
+    alg = orc.EK1(order=3, smooth=smoothed)
+    if adaptive:
+        sol = orc.solve(vf, alg, adaptive=True, dt=2.0**-9, tspan=(0.0, 0.5))
+        kw = dict(adaptive=True, t0=0.0, t1=0.5, dt0=2.0**-9, max_save=256)
+    else:
+        sol = orc.solve(vf, alg, dt=2.0**-6, tspan=(0.0, 0.5))
+        kw = dict(tgrid=np.array(sol.t))
+    # exact stored times are only bit-equal between the two sides on the fixed grid (adaptive times agree to 1e-16)
+    exact = [sol.t[3], sol.t[-2]] if not adaptive else []
+    tq = np.concatenate([np.linspace(0.0, 0.5, 23), exact, [0.5, 0.51, 0.6]])
+    r = E.emul_solve(vf.rhs_id, 3, 3, True, vf.u0[None, :], vf.p, smooth=smoothed, dense_t=tq, **kw)
+    consts = orc.make_consts(3, 3)
+    for j, t in enumerate(tq):
+        ref = orc.dense_output(sol, consts, float(t), smoothed=smoothed)
+        np.testing.assert_allclose(r["qmean"][0][j][:3], ref.mu[:3], rtol=1e-7, atol=1e-10, err_msg=f"t={t}")
+        np.testing.assert_allclose(r["qmean"][0][j], ref.mu, rtol=1e-5, atol=1e-6, err_msg=f"t={t}")
+        c = ref.cov()
+        assert np.abs(r["qcov"][0][j] - c).max() <= 1e-6 * np.abs(c).max() + 1e-300, f"t={t}"

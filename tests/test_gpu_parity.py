@@ -267,3 +267,71 @@ def test_pleiades_adaptive_is_rejected_loudly(pkg):
     prob = pkg.EnsembleProblem(pkg.ODEProblem("pleiades", vf.u0, (0.0, 0.01), ()), u0s=vf.u0[None, :])
     with pytest.raises(pkg.OdefError, match="adaptive stepping is not built"):
         pkg.solve(prob, pkg.EK1(order=3), pkg.EnsembleHIP(), adaptive=True, dt=1e-3)
+
+
+# ---- dense output / saveat (src/solution.jl:165-210) -----------------------------------------------
+
+
+@pytest.mark.parametrize("smooth", [False, True])
+def test_dense_output_fixed_grid(pkg, smooth):
+    vf = orc.vector_field("lorenz63")
+    N, dt, t1 = 70, 2.0**-6, 0.5
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, (0.0, t1), vf.p), perturb_scale=1e-2)
+    sol = pkg.solve(ens, pkg.EK1(order=3, smooth=smooth), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
+    grid = sol.t
+    tq = np.concatenate([np.linspace(0.0, t1, 17), [grid[3], grid[-2], t1, t1 + 0.01]])
+    qm, qc = sol(tq)
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    consts = orc.make_consts(3, 3)
+    for i in (0, 69):
+        ref = orc.solve(vf, orc.EK1(order=3, smooth=smooth), u0=u0s[i], tspan=(0.0, t1), dt=dt)
+        for j, t in enumerate(tq):
+            r = orc.dense_output(ref, consts, float(t), smoothed=smooth)
+            np.testing.assert_allclose(qm[i, j, :3], r.mu[:3], rtol=1e-9, atol=1e-12, err_msg=f"traj {i} t={t}")
+            c = r.cov()
+            assert np.abs(qc[i, j] - c).max() <= 1e-6 * np.abs(c).max() + 1e-300
+    # at stored times the dense output is the stored record itself
+    k = 3
+    np.testing.assert_array_equal(qm[:, 17], (sol.x_smooth_mean() if smooth else sol.x_filt_mean())[:, k])
+    # before t0: NaN record (the reference throws "Invalid t<t0")
+    qm2, _ = sol(np.array([-0.1]))
+    assert np.all(np.isnan(qm2))
+
+
+def test_dense_output_adaptive_common_times(pkg):
+    """BASELINE config 5 at test size: adaptive PI + RTS, posterior compared at saveat = 0:2^-4:t1 with the
+    solver tolerance (as test/correctness.jl:62-66 compares the reference's dense output)."""
+    vf = orc.vector_field("lorenz63")
+    N, t1 = 66, 1.0
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, (0.0, t1), vf.p), perturb_scale=1e-2)
+    sol = pkg.solve(ens, pkg.EK1(order=3), pkg.EnsembleHIP(), trajectories=N, dt=2.0**-9, adaptive=True, max_steps=512)
+    assert sol.retcode == ["Success"] * N
+    tq = np.arange(0.0, t1 + 1e-12, 2.0**-4)
+    qm, _ = sol(tq)
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    consts = orc.make_consts(3, 3)
+    from scipy.integrate import solve_ivp
+
+    for i in (0, 65):
+        ref = orc.solve(vf, orc.EK1(order=3), u0=u0s[i], tspan=(0.0, t1), dt=2.0**-9, adaptive=True)
+        dense = np.array([orc.dense_output(ref, consts, float(t)).mu[:3] for t in tq])
+        np.testing.assert_allclose(qm[i, :, :3], dense, rtol=1e-6, atol=1e-8)
+        truth = solve_ivp(lambda t, u: np.array(vf.f(list(u), vf.p, t)), (0.0, t1), u0s[i], method="DOP853", rtol=1e-12,
+                          atol=1e-12, t_eval=tq).y.T
+        assert np.linalg.norm(qm[i, :, :3] - truth) <= 1e-3 * np.linalg.norm(truth)
+
+
+def test_dense_output_requires_smoothing_and_small_state(pkg):
+    vf = orc.vector_field("lorenz63")
+    ctx = pkg.Context("lorenz63", 3, 1, 64, smooth=True)
+    ctx.set_problem_perturbed(vf.u0, vf.p, 0.0, 1e-2)
+    ctx.solve_fixed(np.arange(9) * 2.0**-9)
+    with pytest.raises(pkg.OdefError, match="odef_smooth has not run"):
+        ctx.dense_output([0.001], True)
+    ctx.close()
+    ctx = pkg.Context("lorenz63", 5, 1, 64, smooth=False)
+    ctx.set_problem_perturbed(vf.u0, vf.p, 0.0, 1e-2)
+    ctx.solve_fixed(np.arange(9) * 2.0**-9)
+    with pytest.raises(pkg.OdefError, match="state dimension <= 12"):
+        ctx.dense_output([0.001], False)
+    ctx.close()
