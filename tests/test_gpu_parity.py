@@ -335,3 +335,50 @@ def test_dense_output_requires_smoothing_and_small_state(pkg):
     with pytest.raises(pkg.OdefError, match="state dimension <= 12"):
         ctx.dense_output([0.001], False)
     ctx.close()
+
+
+# ---- edge cases ------------------------------------------------------------------------------------------
+
+
+def test_single_trajectory_and_single_step(pkg):
+    """N = 1 (one lane of one wave), one step (n_t = 2), and `solve(ODEProblem, ...)` without an ensemble."""
+    vf = orc.vector_field("fhn")
+    prob = pkg.ODEProblem("fhn", vf.u0, (0.0, 7e-2), vf.p)
+    sol = pkg.solve(prob, pkg.EK0(order=1), dt=7e-2, adaptive=False)
+    ref = orc.solve(vf, orc.EK0(order=1), tspan=(0.0, 7e-2), dt=7e-2)
+    assert sol.u.shape == (1, 2, 2) and len(sol.t) == 2
+    np.testing.assert_allclose(sol.u[0], ref.u, rtol=1e-12)
+    assert P.cov_err(sol.x_smooth_cov()[0], ref.covs(smoothed=True)) < 1e-9
+    np.testing.assert_array_equal(sol.x_smooth_mean()[0, -1], sol.x_filt_mean()[0, -1])  # test/smoothing.jl:37
+
+
+def test_config1_fhn_ek0_full(pkg):
+    """BASELINE config 1 (examples/fitzhughnagumo_animation.jl:8-23): FHN, EK0(order=1), dt = 7e-2 on (0, 20)
+    incl. the clipped last step -- through the GPU path, against the oracle."""
+    vf = orc.vector_field("fhn")
+    sol = pkg.solve(pkg.ODEProblem("fhn", vf.u0, vf.tspan, vf.p), pkg.EK0(order=1), dt=7e-2, adaptive=False)
+    ref = orc.solve(vf, orc.EK0(order=1), dt=7e-2)
+    assert len(sol.t) == 287 and sol.t[-1] == 20.0
+    np.testing.assert_allclose(sol.u[0], ref.u, rtol=1e-10)
+    np.testing.assert_allclose(sol.log_likelihood[0], ref.log_likelihood, rtol=1e-8)
+    assert sol.destats.nf[0] == 286 and sol.destats.njacs[0] == 0 and sol.destats.naccept[0] == 286
+
+
+def test_unstable_trajectory_does_not_abort_the_batch(pkg):
+    """A diverging trajectory gets RETCODE Unstable; its neighbours are unaffected (the reference would throw)."""
+    vf = orc.vector_field("lorenz63")
+    u0s = np.tile(vf.u0, (4, 1))
+    u0s[2] = [1e200, 1e200, 1e200]
+    prob = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, (0.0, 0.125), vf.p), u0s=u0s)
+    sol = pkg.solve(prob, pkg.EK1(order=3, smooth=False), pkg.EnsembleHIP(), dt=2.0**-6, adaptive=False)
+    rc = sol.retcode
+    assert rc[2] == "Unstable" and rc[0] == rc[1] == rc[3] == "Success"
+    ref = orc.solve(vf, orc.EK1(order=3, smooth=False), tspan=(0.0, 0.125), dt=2.0**-6)
+    np.testing.assert_allclose(sol.u[3], ref.u, rtol=1e-12)
+
+
+def test_adaptive_max_steps_reports_maxiters(pkg):
+    vf = orc.vector_field("lorenz63")
+    prob = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, (0.0, 2.0), vf.p), u0s=np.tile(vf.u0, (3, 1)))
+    sol = pkg.solve(prob, pkg.EK1(order=3, smooth=False), pkg.EnsembleHIP(), dt=2.0**-9, adaptive=True, max_steps=16)
+    assert sol.retcode == ["MaxIters"] * 3 and np.all(sol.nsaved == 17)
