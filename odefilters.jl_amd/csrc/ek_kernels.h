@@ -87,7 +87,9 @@ struct LaunchDense {
 constexpr int kTeamBig = 256;
 template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kTeamBig) void ek_filter_team_kernel(const TeamFilterParams TP) {
-  TeamFilter<RHS, q, EK1, kTeamBig>::run(TP, (long)blockIdx.x, (int)threadIdx.x);
+  using TF = TeamFilter<RHS, q, EK1, kTeamBig>;
+  __shared__ double sm[TF::W::small_size];
+  TF::run(TP, (long)blockIdx.x, (int)threadIdx.x, sm);
 }
 template <int d, int q>
 __global__ __launch_bounds__(kTeamBig) void rts_smooth_team_kernel(const SmoothParams P, double* ws) {

@@ -10,18 +10,24 @@
 
 namespace odef {
 
+// Workspace of one trajectory, split in two: the D x D-sized buffers live in global memory
+// (`big`, per trajectory), everything small -- including the parts that single threads walk
+// serially (RHS/Jacobian, triangular solves, Householder scalars) -- lives in LDS (`small`).
 template <int d, int NB>
 struct FilterWs {
-  static constexpr int D = d * NB, LD = team_ld(D), d2 = 2 * d;
+  static constexpr int D = d * NB, LD = team_ld(D), d2 = 2 * d, LDd = team_ld(d);
+  // ---- big (global) ----
   static constexpr int X = 0;                    // D x LD   carried covariance / predicted cov / factor + Schur
   static constexpr int Y = X + D * LD;           // D x LD   X A'
   static constexpr int WB = Y + D * LD;          // D x d2   rows of L1, then L1 Q
-  static constexpr int G = WB + D * d2;          // d2 x d   (H L1)'
+  static constexpr int ZT = WB + D * d2;         // d x LD   Zp transposed: ZT[r][l] = (L1 Q)[l][d + r]
+  static constexpr int size = ZT + d * LD;
+  // ---- small (LDS) ----
+  static constexpr int G = 0;                    // d2 x d   (H L1)'
   static constexpr int HV = G + d2 * d;          // d x d2   Householder vectors
   static constexpr int R = HV + d * d2;          // d x d    R factor of S
   static constexpr int H0 = R + d * d;           // d x d    -J pi0
   static constexpr int WM = H0 + d * d;          // d x LDd  H Q H'  (then its Cholesky factor)
-  static constexpr int LDd = team_ld(d);
   static constexpr int M0 = WM + d * LDd;        // d x d
   static constexpr int MV = M0 + d * d;          // m[D]
   static constexpr int MT = MV + D;              // mt[D]
@@ -32,7 +38,8 @@ struct FilterWs {
   static constexpr int DU = UP + d;              // du[d]
   static constexpr int BETA = DU + d;            // beta[d]
   static constexpr int SC = BETA + d;            // scalars: [0] sigma2 [1] zSz [2] logdet [3] loglik acc [4] global diffusion
-  static constexpr int size = SC + 8;
+  static constexpr int COL = SC + 8;             // D        pivot column / per-row scalars
+  static constexpr int small_size = COL + D;
 };
 
 struct TeamFilterParams {
@@ -49,25 +56,27 @@ struct TeamFilter {
   // One step (src/perform_step.jl:27-76).  ws->MV / X: current filter state, updated in place.
   __device__ static inline void step(const Team<TEAM>& t, const PriorConsts& pc, const double* __restrict__ p,
                                      const double* __restrict__ tab, bool fixed_diffusion, int success_iter,
-                                     double* __restrict__ ws) {
+                                     double* __restrict__ ws, double* __restrict__ sm) {
     double* X = ws + W::X;
     double* Y = ws + W::Y;
     double* WB = ws + W::WB;
-    double* G = ws + W::G;
-    double* HV = ws + W::HV;
-    double* R = ws + W::R;
-    double* H0 = ws + W::H0;
-    double* WM = ws + W::WM;
-    double* M0 = ws + W::M0;
-    double* m = ws + W::MV;
-    double* mt = ws + W::MT;
-    double* mp = ws + W::MP;
-    double* z = ws + W::Z;
-    double* y = ws + W::YV;
-    double* up = ws + W::UP;
-    double* du = ws + W::DU;
-    double* beta = ws + W::BETA;
-    double* sc = ws + W::SC;
+    double* ZT = ws + W::ZT;
+    double* G = sm + W::G;
+    double* HV = sm + W::HV;
+    double* R = sm + W::R;
+    double* H0 = sm + W::H0;
+    double* WM = sm + W::WM;
+    double* M0 = sm + W::M0;
+    double* m = sm + W::MV;
+    double* mt = sm + W::MT;
+    double* mp = sm + W::MP;
+    double* z = sm + W::Z;
+    double* y = sm + W::YV;
+    double* up = sm + W::UP;
+    double* du = sm + W::DU;
+    double* beta = sm + W::BETA;
+    double* sc = sm + W::SC;
+    double* col = sm + W::COL;
     const double pi0 = tab[kTabPIJ + 0], pi1 = tab[kTabPIJ + 1], h1 = pi1;
 
     // x~ = P x (src/perform_step.jl:36-38)
@@ -137,7 +146,7 @@ struct TeamFilter {
     // predict_cov! (src/filtering.jl:33-41): X = A Y + sigma2 Q, Cholesky of the first 2d columns
     team_A_mul_plusQ<d, NB, TEAM>(t, pc, Y, sigma2_pred, X);
     t.sync();
-    team_cholesky<D, TEAM>(t, X, d2);
+    team_cholesky_coalesced<D, TEAM>(t, X, d2, col);
     // G = (H L1)' ; rows of L1 into WB
     ODEF_TEAM_FOR(e, d2 * d) {
       const int c = e / d, r = e % d;
@@ -202,15 +211,26 @@ struct TeamFilter {
         sc[4] = (success_iter == 0) ? dt_ : sc[4] + (dt_ - sc[4]) / success_iter;
       }
     }
-    // rows of L1 times Q (src/filtering.jl:85-89): one thread per row
-    ODEF_TEAM_FOR(l, D) {
-      double* w = WB + l * d2;
-      for (int k = 0; k < d; ++k) {
+    // rows of L1 times Q (src/filtering.jl:85-89): per reflector, one dot product per row, then a
+    // coalesced rank-1 update of the D x 2d block
+    for (int k = 0; k < d; ++k) {
+      ODEF_TEAM_FOR(l, D) {
+        const double* w = WB + l * d2;
         double s = 0.0;
         for (int c = k; c < d2; ++c) s += w[c] * HV[k * d2 + c];
-        s *= beta[k];
-        for (int c = k; c < d2; ++c) w[c] -= s * HV[k * d2 + c];
+        col[l] = s * beta[k];
       }
+      t.sync();
+      ODEF_TEAM_FOR(e, D * d2) {
+        const int l = e / d2, c = e % d2;
+        if (c >= k) WB[e] -= col[l] * HV[k * d2 + c];
+      }
+      t.sync();
+    }
+    // Zp transposed, so that the Gram matrix below reads contiguous memory along its fast index
+    ODEF_TEAM_FOR(e, d * D) {
+      const int r = e / D, l = e % D;
+      ZT[r * LD + l] = WB[l * d2 + d + r];
     }
     t.sync();
     ODEF_TEAM_FOR(l, D) {
@@ -223,7 +243,7 @@ struct TeamFilter {
       const int i = e / D, j = e % D;
       if (j <= i) {
         double s = (j >= d2) ? X[i * LD + j] : 0.0;
-        for (int r = 0; r < d; ++r) s += WB[i * d2 + d + r] * WB[j * d2 + d + r];
+        for (int r = 0; r < d; ++r) s += ZT[r * LD + i] * ZT[r * LD + j];
         s *= tab[kTabPIPI + (i / d) * MAXNB + (j / d)];
         X[i * LD + j] = s;
         X[j * LD + i] = s;
@@ -233,13 +253,13 @@ struct TeamFilter {
   }
 
   // whole fixed-step solve of trajectory i
-  __device__ static inline void run(const TeamFilterParams& TP, long i, int tid) {
+  __device__ static inline void run(const TeamFilterParams& TP, long i, int tid, double* __restrict__ sm) {
     const FilterParams& P = TP.fp;
     const Team<TEAM> t{tid};
     double* ws = TP.ws + (size_t)i * W::size;
     double* X = ws + W::X;
-    double* m = ws + W::MV;
-    double* sc = ws + W::SC;
+    double* m = sm + W::MV;
+    double* sc = sm + W::SC;
     const size_t N = (size_t)P.N;
     __attribute__((unused)) double pl_local[RHS::np > 0 ? RHS::np : 1];
     const double* pl = pl_local;
@@ -264,7 +284,7 @@ struct TeamFilter {
     if (P.everystep) save(0);
     for (long n = 0; n < P.nsteps; ++n) {
       const double* tab = P.ptab + (size_t)P.tab_idx[n] * kTabStride;
-      step(t, P.pc, pl, tab, P.fixed_diffusion != 0, (int)n, ws);
+      step(t, P.pc, pl, tab, P.fixed_diffusion != 0, (int)n, ws, sm);
       if (P.everystep) save(n + 1);
     }
     if (!P.everystep) save(0);

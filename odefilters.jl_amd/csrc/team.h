@@ -88,6 +88,34 @@ __device__ inline void team_cholesky(const Team<TEAM>& t, double* __restrict__ X
   }
 }
 
+// Same factorisation for a whole-workgroup team on a matrix in global memory: every access is
+// coalesced (threads run along rows), the pivot column is staged in the shared buffer `col` (D doubles)
+// and the trailing update is applied to the full square so that both triangles stay valid.
+template <int D, int TEAM>
+__device__ inline void team_cholesky_coalesced(const Team<TEAM>& t, double* __restrict__ X, int ncols, double* __restrict__ col) {
+  constexpr int LD = team_ld(D);
+  constexpr int TX = TEAM >= 64 ? 64 : TEAM, TY = TEAM / TX;
+  const int tx = t.tid % TX, ty = t.tid / TX;
+  for (int k = 0; k < ncols; ++k) {
+    ODEF_TEAM_FOR(i, D) col[i] = X[i * LD + k];
+    t.sync();
+    const double piv = col[k];
+    const bool ok = piv > 0.0;
+    const double inv = ok ? 1.0 / piv : 0.0;
+    const double rs = ok ? 1.0 / sqrt(piv) : 0.0;
+    for (int i = k + 1 + ty; i < D; i += TY) {
+      const double ci = col[i] * inv;
+      double* __restrict__ row = X + i * LD;
+      for (int j = k + 1 + tx; j < D; j += TX) row[j] -= ci * col[j];
+    }
+    ODEF_TEAM_FOR(i, D) {
+      if (i > k) X[i * LD + k] = col[i] * rs;
+      else if (i == k) X[k * LD + k] = ok ? sqrt(piv) : 0.0;
+    }
+    t.sync();
+  }
+}
+
 // Rows of G solve  G (L L') = Y  in place (row-parallel):  g = y L^-T, then g = g L^-1.
 template <int D, int TEAM>
 __device__ inline void team_solve_right_spd(const Team<TEAM>& t, const double* __restrict__ L, double* __restrict__ G) {

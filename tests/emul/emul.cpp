@@ -129,9 +129,9 @@ struct RunTeamFilter {
   template <class RHS, int q, bool EK1>
   void operator()() {
     using TF = TeamFilter<RHS, q, EK1, 1>;
-    std::vector<double> ws((size_t)P.N * TF::W::size);
+    std::vector<double> ws((size_t)P.N * TF::W::size), sm(TF::W::small_size);
     TeamFilterParams TP{P, ws.data()};
-    for (long i = 0; i < P.N; ++i) TF::run(TP, i, 0);
+    for (long i = 0; i < P.N; ++i) TF::run(TP, i, 0, sm.data());
   }
 };
 extern "C" int emul_filter_team(const EmulArgs* a) {
