@@ -495,10 +495,16 @@ int odef_solve_fixed(odef_ctx* c, const double* tgrid, int64_t n_t) {
   P.t0 = c->t0;
   int rc;
   if (c->team_path) {
-    if (ensure_ws(c, (size_t)c->cfg.n_traj * team_filter_ws_doubles(c->d, c->q))) return -1;
-    TeamFilterParams TP{P, c->d_ws};
-    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    rc = launch_filter_pleiades(c->q, c->cfg.alg == ODEF_EK1, TP, c->stream);
+    const char* path = getenv("ODEF_PLEIADES_PATH");  // "team": the global-workspace kernel, for A/B comparison
+    if (path && std::strcmp(path, "team") == 0) {
+      if (ensure_ws(c, (size_t)c->cfg.n_traj * team_filter_ws_doubles(c->d, c->q))) return -1;
+      TeamFilterParams TP{P, c->d_ws};
+      HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+      rc = launch_filter_pleiades(c->q, c->cfg.alg == ODEF_EK1, TP, c->stream);
+    } else {
+      HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+      rc = launch_filter_pleiades_tiles(c->q, c->cfg.alg == ODEF_EK1, P, c->stream);
+    }
   } else {
     // one lane per trajectory: the per-field buffer descriptors carry 32-bit sizes
     if ((size_t)c->TRI * (size_t)c->cfg.n_traj * sizeof(double) >= (1ull << 31))

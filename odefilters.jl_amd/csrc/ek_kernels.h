@@ -9,6 +9,7 @@
 #include "smooth_lane.h"
 #include "dense_lane.h"
 #include "filter_team.h"
+#include "filter_tiles.h"
 #include "launch.h"
 
 namespace odef {
@@ -95,6 +96,23 @@ template <int d, int q>
 __global__ __launch_bounds__(kTeamBig) void rts_smooth_team_kernel(const SmoothParams P, double* ws) {
   smooth_team_lane<d, q, kTeamBig>(P, (long)blockIdx.x, (int)threadIdx.x, ws + (size_t)blockIdx.x * SmoothWs<d, q + 1>::size);
 }
+
+// Register-tiled workgroup-per-trajectory filter (filter_tiles.h): 320 threads, one 7 x 7 covariance tile each.
+template <class RHS, int q, bool EK1>
+__global__ __launch_bounds__(kTilesThreads) void ek_filter_tiles_kernel(const FilterParams P) {
+  using TF = TilesFilter<RHS, q, EK1>;
+  __shared__ double sm[TF::W::size];
+  TileState st;
+  TF::run(P, (long)blockIdx.x, (int)threadIdx.x, sm, &st);
+}
+struct LaunchTilesFilter {
+  const FilterParams& P;
+  hipStream_t s;
+  template <class RHS, int q, bool EK1>
+  void operator()() {
+    hipLaunchKernelGGL((ek_filter_tiles_kernel<RHS, q, EK1>), dim3((unsigned)P.N), dim3(kTilesThreads), 0, s, P);
+  }
+};
 
 struct LaunchTeamFilter {
   const TeamFilterParams& TP;

@@ -1,0 +1,608 @@
+// Fixed-step EK0/EK1 filter for large state dimension (Pleiades: d = 28, D = 168), one workgroup
+// of 320 threads per trajectory with the packed covariance DISTRIBUTED IN REGISTERS: thread t owns
+// one 7 x 7 tile of the lower triangle (24 x 25 / 2 = 300 tiles at D = 168) for the whole solve; LDS
+// (<= 160 KB) is only the exchange medium.  Same arithmetic as EKStep::run (ek_math.h):
+//   congruence  A S A' + sigma2 Q     every thread gathers the <= 36 source tiles of its tile from LDS
+//   partial Cholesky (first 2d cols)  pivot column published to LDS, rank-1 update of the own tile
+//   Householder QR of (H L1)'         small, in LDS
+//   rows of L1 times Q                one thread per row, row in registers, reflectors broadcast from LDS
+//   S_filt = Zp Zp' + Schur           own tile: 7 x 7 x d FMAs on 14 rows of Zp read from LDS; the Schur
+//                                     part never leaves the registers
+// The body is a sequence of PHASES separated by __syncthreads(); the host emulation (tests/emul) runs
+// each phase for all threads in turn over an array of TileStates -- same source.
+#pragma once
+#include "ek_lane.h"
+#include "team.h"
+
+namespace odef {
+
+constexpr int kTile = 7;
+constexpr int kTilesThreads = 320;
+
+template <int d, int NB>
+struct TilesLds {
+  static constexpr int D = d * NB, nT = D / kTile, ntiles = nT * (nT + 1) / 2, d2 = 2 * d;
+  static constexpr int LDL = d2 + 1, LDZ = d + 1, LDd = team_ld(d), T2 = kTile * kTile;
+  // region A, time-shared: tile exchange EX[ntiles][49]  |  L1[D][LDL] + ZP[D][LDZ]
+  static constexpr int EX = 0, L1 = 0, ZP = D * LDL;
+  static constexpr int A_size = (ntiles * T2 > D * LDL + D * LDZ) ? ntiles * T2 : D * LDL + D * LDZ;
+  // region B, time-shared: WM[d][LDd] + M0[d][d]  |  HV[d][d2] + R[d][d]
+  static constexpr int WM = A_size, M0 = WM + d * LDd, HV = A_size, R = HV + d * d2;
+  static constexpr int B_size = (d * LDd + d * d > d * d2 + d * d) ? d * LDd + d * d : d * d2 + d * d;
+  static constexpr int G = A_size + B_size;  // d2 x d
+  static constexpr int H0 = G + d2 * d;      // d x d
+  static constexpr int MV = H0 + d * d, MT = MV + D, MP = MT + D, Z = MP + D, YV = Z + d, UP = YV + d, DU = UP + d;
+  static constexpr int BETA = DU + d, SC = BETA + d, COL = SC + 8, size = COL + D + d;  // col: D entries + d column sums
+  static_assert(d % kTile == 0, "tile size must divide the ODE dimension");
+  static_assert(ntiles <= kTilesThreads && D <= kTilesThreads, "one thread per tile / per state row");
+};
+
+struct TileState {
+  double x[kTile][kTile];
+  double aj[MAXNB], ak[MAXNB];  // rows Jb = I/tpb and Kb = J/tpb of At: coefficients of this tile's congruence
+  double qjk;                   // Qt[Jb][Kb]
+  int I, J, tile;               // tile row / column / linear index; I < 0: this thread owns no tile
+};
+
+// In-kernel cycle stamps at phase boundaries: ONLY in the diagnostic build of tools/tiles_stamps.hip
+// (-DODEF_TILES_STAMPS); the product kernel contains none.
+#ifdef ODEF_TILES_STAMPS
+#define ODEF_STAMP(k)                                                                        \
+  if (tid_dev == 0 && blockIdx.x == 0 && g_stamp_buf) {                                                       \
+    unsigned long long t_;                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+    g_stamp_buf[(k)] += t_ - g_stamp_last;                                                   \
+    g_stamp_last = t_;                                                                       \
+  }
+__device__ unsigned long long* g_stamp_buf = nullptr;
+__device__ unsigned long long g_stamp_last = 0;
+#else
+#define ODEF_STAMP(k)
+#endif
+
+#ifdef ODEF_HOST_EMUL
+#define ODEF_TILES_PHASE(...)                                              \
+  for (int tid = 0; tid < kTilesThreads; ++tid) {                          \
+    TileState& S = st[tid];                                                \
+    (void)S;                                                               \
+    __VA_ARGS__                                                            \
+  }
+#else
+#define ODEF_TILES_PHASE(...)                                              \
+  {                                                                        \
+    const int tid = tid_dev;                                               \
+    TileState& S = st[0];                                                  \
+    (void)S; (void)tid;                                                    \
+    __VA_ARGS__                                                            \
+  }                                                                        \
+  __syncthreads();
+#endif
+
+template <class RHS, int q, bool IS_EK1>
+struct TilesFilter {
+  static constexpr int d = RHS::d, NB = q + 1, D = d * NB, TRI = D * (D + 1) / 2, d2 = 2 * d;
+  using W = TilesLds<d, NB>;
+  static constexpr int NT = kTilesThreads, TS = kTile, T2 = TS * TS, tpb = d / TS;  // tiles per derivative block
+
+  __device__ static inline void step(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab,
+                                     bool fixed_diffusion, int success_iter, double* __restrict__ sm, TileState* st,
+                                     int tid_dev) {
+    (void)tid_dev;
+    double* EX = sm + W::EX;
+    double* L1 = sm + W::L1;
+    double* ZP = sm + W::ZP;
+    double* WM = sm + W::WM;
+    double* M0 = sm + W::M0;
+    double* HV = sm + W::HV;
+    double* R = sm + W::R;
+    double* G = sm + W::G;
+    double* H0 = sm + W::H0;
+    double* m = sm + W::MV;
+    double* mt = sm + W::MT;
+    double* mp = sm + W::MP;
+    double* z = sm + W::Z;
+    double* y = sm + W::YV;
+    double* up = sm + W::UP;
+    double* du = sm + W::DU;
+    double* beta = sm + W::BETA;
+    double* sc = sm + W::SC;
+    double* col = sm + W::COL;
+    const double pi0 = tab[kTabPIJ + 0], pi1 = tab[kTabPIJ + 1], h1 = pi1;
+
+    ODEF_STAMP(0)
+    // x~ = P x (src/perform_step.jl:36-38): mean in LDS, covariance tile in registers
+    ODEF_TILES_PHASE(
+      if (tid < D) mt[tid] = tab[kTabPJ + tid / d] * m[tid];
+      if (S.I >= 0) {
+        const double pp = tab[kTabPP + (S.I / tpb) * MAXNB + (S.J / tpb)];
+        _Pragma("unroll")
+        for (int r = 0; r < TS; ++r)
+          _Pragma("unroll")
+          for (int c = 0; c < TS; ++c) {
+            S.x[r][c] *= pp;
+            EX[S.tile * T2 + r * TS + c] = S.x[r][c];
+          }
+      }
+    )
+    // m^- = A m~ , u_pred  (src/filtering.jl:22-25, src/perform_step.jl:43)
+    ODEF_TILES_PHASE(
+      if (tid < D) {
+        const int J = tid / d;
+        const int a = tid % d;
+        double s = mt[tid];
+        for (int j = J + 1; j < NB; ++j) s += pc.At[J][j] * mt[j * d + a];
+        mp[tid] = s;
+        if (tid < d) up[tid] = pi0 * s;
+      }
+    )
+    ODEF_STAMP(1)
+    // measure! (src/perform_step.jl:95-132): vector field and Jacobian by one thread
+    if constexpr (HasTeamEval<RHS>::value) {
+      // many-thread evaluation; the pair buffer borrows region B (W / M0 are built afterwards)
+      static_assert(RHS::team_scratch <= W::B_size, "pair buffer must fit region B");
+      ODEF_TILES_PHASE(
+        RHS::team_eval_pairs(tid, up, WM);
+      )
+      ODEF_TILES_PHASE(
+        RHS::team_eval_assemble(tid, NT, up, WM, du, IS_EK1 ? H0 : nullptr);  // raw J into H0, scaled below
+      )
+    } else {
+      ODEF_TILES_PHASE(
+        if (tid == 0) {
+          double u_[d];
+          double du_[d];
+          for (int a = 0; a < d; ++a) u_[a] = up[a];
+          RHS::f(u_, p, du_);
+          for (int a = 0; a < d; ++a) du[a] = du_[a];
+          if constexpr (IS_EK1) RHS::jac(u_, p, *reinterpret_cast<double (*)[d][d]>(H0));  // raw J, scaled below
+        }
+      )
+    }
+    ODEF_STAMP(2)
+    ODEF_TILES_PHASE(
+      if (tid < d) z[tid] = pi1 * mp[d + tid] - du[tid];
+      for (int e = tid; e < d * d; e += NT) {  // H0 = -J pi0 ; M0 = H0 QL00 + I h1 QL10 (src/diffusions.jl:78)
+        const int r = e / d;
+        const int a = e % d;
+        double h0 = 0.0;
+        if constexpr (IS_EK1) h0 = (0.0 - H0[e]) * pi0;
+        H0[e] = h0;
+        M0[e] = h0 * pc.QLt[0][0] + (r == a ? h1 * pc.QLt[1][0] : 0.0);
+      }
+    )
+    ODEF_TILES_PHASE(
+      const double m1 = h1 * pc.QLt[1][1];
+      for (int e = tid; e < d * d; e += NT) {
+        const int r = e / d;
+        const int s_ = e % d;
+        double acc = (r == s_) ? m1 * m1 : 0.0;
+        for (int a = 0; a < d; ++a) acc += M0[r * d + a] * M0[s_ * d + a];
+        WM[r * W::LDd + s_] = acc;
+      }
+    )
+    ODEF_STAMP(3)
+    double sigma2_pred = 1.0;
+    if (!fixed_diffusion) {  // sigma^2 = |Lw^-1 z|^2 / d  (src/diffusions.jl:72-80)
+      for (int k = 0; k < d; ++k) {  // right-looking Cholesky of W in LDS, one thread per row
+        ODEF_TILES_PHASE(
+          if (tid < d) col[tid] = WM[tid * W::LDd + k];
+        )
+        ODEF_TILES_PHASE(
+          if (tid < d && tid >= k) {
+            const double piv = col[k];
+            const bool ok = piv > 0.0;
+            const double inv = ok ? 1.0 / piv : 0.0;
+            const double ci = col[tid] * inv;
+            double* row = WM + tid * W::LDd;
+            static_for<0, d / 7>([&](auto bb) {  // batches of 7 independent LDS reads
+              constexpr int j0 = decltype(bb)::value * 7;
+              double cj[7];
+              double w[7];
+_Pragma("unroll")
+              for (int jj = 0; jj < 7; ++jj) {
+                cj[jj] = col[j0 + jj];
+                w[jj] = row[j0 + jj];
+              }
+_Pragma("unroll")
+              for (int jj = 0; jj < 7; ++jj) {
+                const int j = j0 + jj;
+                if (j > k && j <= tid && tid > k) row[j] = w[jj] - ci * cj[jj];
+              }
+            });
+            row[k] = (tid > k) ? col[tid] * (ok ? 1.0 / sqrt(piv) : 0.0) : (ok ? sqrt(piv) : 0.0);
+          }
+        )
+      }
+      ODEF_TILES_PHASE(
+        if (tid == 0) {  // forward substitution with the solution kept in registers (independent LDS reads)
+          double yv[d];
+          double acc = 0.0;
+          static_for<0, d>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            double s = z[r];
+_Pragma("unroll")
+            for (int c = 0; c < r; ++c) s -= WM[r * W::LDd + c] * yv[c];
+            yv[r] = s / WM[r * W::LDd + r];
+            acc += yv[r] * yv[r];
+          });
+          sc[0] = acc / d;
+          sc[4] = acc / d;
+        }
+      )
+      sigma2_pred = sc[0];
+    }
+    ODEF_STAMP(4)
+    // predict_cov! (src/filtering.jl:33-41): own tile of A S A' + sigma2 Q from the published tiles
+    ODEF_TILES_PHASE(
+      if (S.I >= 0) {
+        const int Jb = S.I / tpb;
+        const int si = S.I % tpb;
+        const int Kb = S.J / tpb;
+        const int sj = S.J % tpb;
+        double acc[TS][TS];
+_Pragma("unroll")
+        for (int r = 0; r < TS; ++r)
+_Pragma("unroll")
+          for (int c = 0; c < TS; ++c) acc[r][c] = 0.0;
+        static_for<0, NB * NB>([&](auto jk) {  // compile-time (j, k): the coefficient rows stay in registers
+          constexpr int j = decltype(jk)::value / NB;
+          constexpr int k = decltype(jk)::value % NB;
+          if (j >= Jb && k >= Kb) {
+            const double coef = S.aj[j] * S.ak[k];
+            const int rt = j * tpb + si;
+            const int ct = k * tpb + sj;
+            const bool lower = rt >= ct;
+            const double* src = EX + (lower ? (rt * (rt + 1) / 2 + ct) : (ct * (ct + 1) / 2 + rt)) * T2;
+            const int sr = lower ? TS : 1;  // element (r, c) of the source tile, transposed when it is stored as (ct, rt)
+            const int scs = lower ? 1 : TS;
+_Pragma("unroll")
+            for (int r = 0; r < TS; ++r) {
+              double v[TS];
+_Pragma("unroll")
+              for (int c = 0; c < TS; ++c) v[c] = src[r * sr + c * scs];
+_Pragma("unroll")
+              for (int c = 0; c < TS; ++c) acc[r][c] += coef * v[c];
+            }
+          }
+        });
+        if (si == sj) {
+_Pragma("unroll")
+          for (int r = 0; r < TS; ++r) acc[r][r] += sigma2_pred * S.qjk;
+        }
+_Pragma("unroll")
+        for (int r = 0; r < TS; ++r)
+_Pragma("unroll")
+          for (int c = 0; c < TS; ++c) S.x[r][c] = acc[r][c];
+      }
+    )
+    ODEF_STAMP(5)
+    // Cholesky of the first 2d columns, right-looking; the tiles right of them end as the Schur complement
+    for (int kt = 0; kt < d2 / TS; ++kt) static_for<0, TS>([&](auto kcc) {
+      constexpr int kc = decltype(kcc)::value;  // column inside the tile: compile-time, so the tile stays in registers
+      const int k = kt * TS + kc;
+      ODEF_TILES_PHASE(
+        if (S.I >= 0 && S.J == kt) {
+          _Pragma("unroll")
+          for (int r = 0; r < TS; ++r) {
+            const int i = S.I * TS + r;
+            if (i >= k) col[i] = S.x[r][kc];
+          }
+        }
+      )
+      ODEF_TILES_PHASE(
+        if (S.I >= 0 && S.J >= kt) {
+          const double piv = col[k];
+          const bool ok = piv > 0.0;  // failing pivot: the reference's QR-fallback case (src/filtering.jl:38-47)
+          const double inv = ok ? 1.0 / piv : 0.0;
+          // stage the 14 column entries this tile needs, zeroing those outside the trailing block
+          double ci[TS];
+          double cj[TS];
+_Pragma("unroll")
+          for (int r = 0; r < TS; ++r) {
+            const int i = S.I * TS + r;
+            const int j = S.J * TS + r;
+            const double vi = col[i];
+            const double vj = col[j];
+            ci[r] = (i > k) ? vi * inv : 0.0;
+            cj[r] = (j > k) ? vj : 0.0;
+          }
+_Pragma("unroll")
+          for (int r = 0; r < TS; ++r)
+_Pragma("unroll")
+            for (int c = 0; c < TS; ++c) S.x[r][c] -= ci[r] * cj[c];
+          if (S.J == kt) {
+            const double rs = ok ? 1.0 / sqrt(piv) : 0.0;
+            const double dg = ok ? sqrt(piv) : 0.0;
+_Pragma("unroll")
+            for (int r = 0; r < TS; ++r) {
+              const int i = S.I * TS + r;
+              const double lv = col[i] * rs;
+              S.x[r][kc] = (i > k) ? lv : ((i == k) ? dg : S.x[r][kc]);
+            }
+          }
+        }
+      )
+    });
+    ODEF_STAMP(6)
+    // publish L1 (lower-trapezoidal D x 2d) to LDS
+    ODEF_TILES_PHASE(
+      for (int e = tid; e < d2 * W::LDL; e += NT) L1[e] = 0.0;  // rows < 2d: the part above the diagonal
+    )
+    ODEF_TILES_PHASE(
+      if (S.I >= 0 && S.J < d2 / TS) {
+        _Pragma("unroll")
+        for (int r = 0; r < TS; ++r)
+          _Pragma("unroll")
+          for (int c = 0; c < TS; ++c) {
+            const int i = S.I * TS + r;
+            const int j = S.J * TS + c;
+            if (j <= i) L1[i * W::LDL + j] = S.x[r][c];
+          }
+      }
+    )
+    // G = (H L1)'  (2d x d)
+    ODEF_TILES_PHASE(
+      for (int e = tid; e < d2 * d; e += NT) {
+        const int c = e / d;
+        const int r = e % d;
+        double s = 0.0;
+        if constexpr (IS_EK1) {
+          for (int k = c; k < d; ++k) s += H0[r * d + k] * L1[k * W::LDL + c];
+        }
+        if (d + r >= c) s += h1 * L1[(d + r) * W::LDL + c];
+        G[c * d + r] = s;
+      }
+    )
+    ODEF_STAMP(7)
+    // Householder QR of G: threads < 2d store the reflector, threads in (k, d) update their column
+    // One thread per ROW of G (2d threads).  Per reflector k: (A) publish column k, (B) every row thread
+    // derives the reflector scalars from the published column and publishes v_i * G[i][c], (C) thread c
+    // sums its column of partial products, (D) every row thread updates its row.  All LDS reads are
+    // issued in independent batches.
+    double* PB = ZP;          // 2d x LDZ partial products (region ZP is free until the row phase)
+    double* sbuf = col + D;   // d column sums
+    for (int k = 0; k < d; ++k) {
+      ODEF_TILES_PHASE(
+        if (tid < d2) col[tid] = (tid >= k) ? G[tid * d + k] : 0.0;
+      )
+      ODEF_TILES_PHASE(
+        if (tid < d2) {
+          double nrm2 = 0.0;
+          static_for<0, d2 / 7>([&](auto bb) {
+            constexpr int i0 = decltype(bb)::value * 7;
+            double v[7];
+_Pragma("unroll")
+            for (int ii = 0; ii < 7; ++ii) v[ii] = col[i0 + ii];
+_Pragma("unroll")
+            for (int ii = 0; ii < 7; ++ii) nrm2 += v[ii] * v[ii];
+          });
+          const double nrm = sqrt(nrm2);
+          const double x0 = col[k];
+          const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+          const double v0 = x0 - alpha;
+          const double vtv = nrm2 - x0 * x0 + v0 * v0;
+          const double bt = (vtv > 0.0) ? 2.0 / vtv : 0.0;
+          const double vi = (tid == k) ? v0 : col[tid];  // zero for rows above k
+          if (tid >= k) HV[k * d2 + tid] = vi;
+          if (tid == 0) {
+            beta[k] = bt;
+            R[k * d + k] = alpha;
+          }
+          static_for<0, d / 7>([&](auto bb) {
+            constexpr int c0 = decltype(bb)::value * 7;
+            double g[7];
+_Pragma("unroll")
+            for (int cc = 0; cc < 7; ++cc) g[cc] = G[tid * d + c0 + cc];
+_Pragma("unroll")
+            for (int cc = 0; cc < 7; ++cc) PB[tid * W::LDZ + c0 + cc] = vi * g[cc];
+          });
+        }
+      )
+      ODEF_TILES_PHASE(
+        if (tid < d) {
+          double sacc = 0.0;
+          static_for<0, d2 / 7>([&](auto bb) {
+            constexpr int i0 = decltype(bb)::value * 7;
+            double v[7];
+_Pragma("unroll")
+            for (int ii = 0; ii < 7; ++ii) v[ii] = PB[(i0 + ii) * W::LDZ + tid];
+_Pragma("unroll")
+            for (int ii = 0; ii < 7; ++ii) sacc += v[ii];
+          });
+          sbuf[tid] = sacc * beta[k];
+        }
+      )
+      ODEF_TILES_PHASE(
+        if (tid < d2 && tid >= k) {
+          const double vi = (tid == k) ? HV[k * d2 + k] : col[tid];
+          static_for<0, d / 7>([&](auto bb) {
+            constexpr int c0 = decltype(bb)::value * 7;
+            double g[7];
+            double sv[7];
+_Pragma("unroll")
+            for (int cc = 0; cc < 7; ++cc) {
+              g[cc] = G[tid * d + c0 + cc];
+              sv[cc] = sbuf[c0 + cc];
+            }
+_Pragma("unroll")
+            for (int cc = 0; cc < 7; ++cc) {
+              const int c = c0 + cc;
+              if (c > k) {
+                const double gn = g[cc] - sv[cc] * vi;
+                G[tid * d + c] = gn;
+                if (tid == k) R[k * d + c] = gn;
+              }
+            }
+          });
+        }
+      )
+    }
+    ODEF_STAMP(8)
+    // y = R^-T z ; z'S^-1 z ; log det S  (src/perform_step.jl:66)
+    ODEF_TILES_PHASE(
+      if (tid == 0) {
+        double zSz = 0.0;
+        double logacc = 0.0;
+        double yv[d];
+        static_for<0, d>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          double s = z[r];
+_Pragma("unroll")
+          for (int c = 0; c < r; ++c) s -= R[c * d + r] * yv[c];
+          yv[r] = s / R[r * d + r];
+          y[r] = yv[r];
+          zSz += yv[r] * yv[r];
+          logacc += log(fabs(R[r * d + r]));
+        });
+        sc[1] = zSz;
+        sc[3] += -0.5 * (zSz + 2.0 * logacc + d * 1.8378770664093453);
+        if (fixed_diffusion) {  // src/diffusions.jl:11-36
+          const double dt_ = zSz / d;
+          sc[0] = dt_;
+          sc[4] = (success_iter == 0) ? dt_ : sc[4] + (dt_ - sc[4]) / success_iter;
+        }
+      }
+    )
+    ODEF_STAMP(9)
+    // rows of L1 times Q (src/filtering.jl:85-89): one thread per row, the row in registers
+    ODEF_TILES_PHASE(
+      if (tid < D) {
+        double w[d2];
+_Pragma("unroll")
+        for (int c = 0; c < d2; ++c) w[c] = L1[tid * W::LDL + c];
+        static_for<0, d>([&](auto kc_) {
+          constexpr int k = decltype(kc_)::value;
+          double s = 0.0;
+_Pragma("unroll")
+          for (int c = k; c < d2; ++c) s += w[c] * HV[k * d2 + c];
+          s *= beta[k];
+_Pragma("unroll")
+          for (int c = k; c < d2; ++c) w[c] -= s * HV[k * d2 + c];
+        });
+        double s = mp[tid];
+_Pragma("unroll")
+        for (int r = 0; r < d; ++r) s -= w[r] * y[r];
+        m[tid] = tab[kTabPIJ + tid / d] * s;  // un-precondition (src/perform_step.jl:75)
+_Pragma("unroll")
+        for (int r = 0; r < d; ++r) ZP[tid * W::LDZ + r] = w[d + r];
+      }
+    )
+    ODEF_STAMP(10)
+    // Sigma_filt = Zp Zp' + Schur (own tile), un-preconditioned
+    ODEF_TILES_PHASE(
+      if (S.I >= 0) {
+        const bool schur = S.J >= d2 / TS;
+        double acc[TS][TS];
+        _Pragma("unroll")
+        for (int r = 0; r < TS; ++r)
+          _Pragma("unroll")
+          for (int c = 0; c < TS; ++c) acc[r][c] = schur ? S.x[r][c] : 0.0;
+        const double* zi = ZP + (S.I * TS) * W::LDZ;
+        const double* zj = ZP + (S.J * TS) * W::LDZ;
+        for (int kk = 0; kk < d; ++kk) {
+          double a_[TS];
+          double b_[TS];
+          _Pragma("unroll")
+          for (int r = 0; r < TS; ++r) {
+            a_[r] = zi[r * W::LDZ + kk];
+            b_[r] = zj[r * W::LDZ + kk];
+          }
+          _Pragma("unroll")
+          for (int r = 0; r < TS; ++r)
+            _Pragma("unroll")
+            for (int c = 0; c < TS; ++c) acc[r][c] += a_[r] * b_[c];
+        }
+        const double pipi = tab[kTabPIPI + (S.I / tpb) * MAXNB + (S.J / tpb)];
+        _Pragma("unroll")
+        for (int r = 0; r < TS; ++r)
+          _Pragma("unroll")
+          for (int c = 0; c < TS; ++c) S.x[r][c] = acc[r][c] * pipi;
+      }
+    )
+    ODEF_STAMP(11)
+  }
+
+  // whole fixed-step solve of trajectory i.  `st`: one TileState (device) / kTilesThreads of them (host).
+  __device__ static inline void run(const FilterParams& P, long i, int tid_dev, double* __restrict__ sm, TileState* st) {
+    double* m = sm + W::MV;
+    double* sc = sm + W::SC;
+    const size_t N = (size_t)P.N;
+    __attribute__((unused)) double pl_local[RHS::np > 0 ? RHS::np : 1];
+    const double* pl = pl_local;
+    for (int k = 0; k < RHS::np; ++k) pl_local[k] = P.p_shared ? P.p[k] : P.p[(size_t)k * N + i];
+    ODEF_TILES_PHASE(
+      S.I = -1;
+      S.J = -1;
+      S.tile = tid;
+      if (tid < W::ntiles) {
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= tid) ++I;
+        S.I = I;
+        S.J = tid - I * (I + 1) / 2;
+      }
+      for (int j = 0; j < MAXNB; ++j) {
+        S.aj[j] = 0.0;
+        S.ak[j] = 0.0;
+      }
+      S.qjk = 0.0;
+      if (S.I >= 0) {
+        for (int Jb = 0; Jb < NB; ++Jb)
+          for (int j = 0; j < NB; ++j) {
+            if (Jb == S.I / tpb) S.aj[j] = P.pc.At[Jb][j];
+            if (Jb == S.J / tpb) S.ak[j] = P.pc.At[Jb][j];
+            if (Jb == S.I / tpb && j == S.J / tpb) S.qjk = P.pc.Qt[Jb][j];
+          }
+      }
+      _Pragma("unroll")
+      for (int r = 0; r < TS; ++r)
+        _Pragma("unroll")
+        for (int c = 0; c < TS; ++c) S.x[r][c] = 0.0;
+      if (tid == 0) {
+        double u0[d];
+        double m0[D];
+        for (int a = 0; a < d; ++a) u0[a] = P.u0[(size_t)a * N + i];
+        taylor_init<RHS, q>(u0, pl, m0);
+        for (int k = 0; k < D; ++k) m[k] = m0[k];
+        for (int k = 0; k < 8; ++k) sc[k] = 0.0;
+      }
+    )
+    auto save = [&](long slot) {
+      ODEF_TILES_PHASE(
+        if (tid < D) P.mean[((size_t)slot * D + tid) * N + i] = m[tid];
+        if (S.I >= 0) {
+          _Pragma("unroll")
+          for (int r = 0; r < TS; ++r)
+            _Pragma("unroll")
+            for (int c = 0; c < TS; ++c) {
+              const int a = S.I * TS + r;
+              const int b = S.J * TS + c;
+              if (b <= a) P.cov[((size_t)slot * TRI + tri(a, b)) * N + i] = S.x[r][c];
+            }
+        }
+        if (tid == 0) P.diff[(size_t)slot * N + i] = (slot == 0 && P.everystep) ? 0.0 : sc[4];
+      )
+    };
+    if (P.everystep) save(0);
+    for (long n = 0; n < P.nsteps; ++n) {
+      const double* tab = P.ptab + (size_t)P.tab_idx[n] * kTabStride;
+      step(P.pc, pl, tab, P.fixed_diffusion != 0, (int)n, sm, st, tid_dev);
+      if (P.everystep) save(n + 1);
+    }
+    if (!P.everystep) save(0);
+    ODEF_TILES_PHASE(
+      if (tid == 0) {
+        P.loglik[i] = sc[3];
+        P.naccept[i] = (int)P.nsteps;
+        P.nreject[i] = 0;
+        P.nf[i] = (int)P.nsteps;
+        P.njac[i] = IS_EK1 ? (int)P.nsteps : 0;
+        P.nsaved[i] = P.everystep ? (int)P.nsteps + 1 : 1;
+        bool ok = true;
+        for (int k = 0; k < D; ++k) ok = ok && (fabs(m[k]) <= 1.79769313486231570815e+308);
+        P.retcode[i] = ok ? 0 : 3;
+      }
+    )
+  }
+};
+
+}  // namespace odef

@@ -4,6 +4,10 @@ int launch_filter_pleiades(int q, int ek1, const TeamFilterParams& TP, hipStream
   LaunchTeamFilter f{TP, s};
   return dispatch_order<RhsPleiades>(q, ek1, f);
 }
+int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s) {
+  LaunchTilesFilter f{P, s};
+  return dispatch_order<RhsPleiades>(q, ek1, f);
+}
 int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s) {
   LaunchTeamSmooth f{P, ws, s};
   return dispatch_smooth_order<28>(q, f);

@@ -103,6 +103,13 @@ template <int NC>
 __device__ inline Jet<NC> inv_r3(const Jet<NC>& r2) { return jet_pow(r2, -1.5); }
 
 // ---- the registry ----------------------------------------------------------------------
+// Optional: a vector field may provide `team_eval_pairs` / `team_eval_assemble` (see RhsPleiades) so that
+// the workgroup-per-trajectory kernels evaluate f and J with many threads instead of one.
+template <class RHS, class = void>
+struct HasTeamEval { static constexpr bool value = false; };
+template <class RHS>
+struct HasTeamEval<RHS, std::enable_if_t<RHS::has_team_eval>> { static constexpr bool value = true; };
+
 
 struct RhsFHN {  // examples/fitzhughnagumo_animation.jl:8-16, README.md:36-44
   static constexpr int d = 2, np = 3, id = 0;
@@ -235,6 +242,72 @@ struct RhsPleiades {
         J[21 + i][j] += axy;      J[21 + i][i] -= axy;
         J[21 + i][7 + j] += ayy;  J[21 + i][7 + i] -= ayy;
       }
+  }
+
+  // Team evaluation for the workgroup-per-trajectory kernels: the 42 ordered pair interactions are
+  // computed by 42 threads into `pairbuf` (5 x 49 doubles), then du (28 entries) and the raw Jacobian
+  // (28 x 28, row-major) are assembled element-parallel.  Two calls with a barrier in between.
+  static constexpr bool has_team_eval = true;
+  static constexpr int team_scratch = 5 * 49;
+  __device__ static void team_eval_pairs(int tid, const double* u, double* pairbuf) {
+    if (tid < 49) {
+      const int i = tid / 7, j = tid % 7;
+      double axx = 0.0, axy = 0.0, ayy = 0.0, fx = 0.0, fy = 0.0;
+      if (i != j) {
+        const double mj = j + 1.0;
+        const double dx = u[j] - u[i], dy = u[7 + j] - u[7 + i];
+        const double r2 = dx * dx + dy * dy;
+        const double r3 = 1.0 / (r2 * sqrt(r2));
+        const double r5 = r3 / r2;
+        axx = mj * (r3 - 3.0 * dx * dx * r5);
+        axy = mj * (-3.0 * dx * dy * r5);
+        ayy = mj * (r3 - 3.0 * dy * dy * r5);
+        fx = (mj * r3) * dx;
+        fy = (mj * r3) * dy;
+      }
+      pairbuf[0 * 49 + tid] = axx;
+      pairbuf[1 * 49 + tid] = axy;
+      pairbuf[2 * 49 + tid] = ayy;
+      pairbuf[3 * 49 + tid] = fx;
+      pairbuf[4 * 49 + tid] = fy;
+    }
+  }
+  __device__ static void team_eval_assemble(int tid, int nthreads, const double* u, const double* pairbuf, double* du,
+                                            double* Jraw /* may be null (EK0) */) {
+    if (tid < 28) {
+      double v;
+      if (tid < 14) {
+        v = u[14 + tid];
+      } else {
+        const int i = (tid - 14) % 7;
+        const double* f = pairbuf + (tid < 21 ? 3 : 4) * 49 + i * 7;
+        v = 0.0;
+        for (int j = 0; j < 7; ++j) v += f[j];  // the i == j entry is zero
+      }
+      du[tid] = v;
+    }
+    if (Jraw) {
+      for (int e = tid; e < 28 * 28; e += nthreads) {
+        const int r = e / 28, c = e % 28;
+        double v = 0.0;
+        if (r < 14) {
+          v = (c == r + 14) ? 1.0 : 0.0;
+        } else if (c < 14) {
+          const int i = (r - 14) % 7, j = c % 7;
+          // block (x-acc | y-acc) x (x | y): axx, axy / axy, ayy
+          const int which = (r < 21) ? (c < 7 ? 0 : 1) : (c < 7 ? 1 : 2);
+          const double* a = pairbuf + which * 49 + i * 7;
+          if (j != i) {
+            v = a[j];
+          } else {
+            double sacc = 0.0;
+            for (int jj = 0; jj < 7; ++jj) sacc += a[jj];
+            v = -sacc;
+          }
+        }
+        Jraw[e] = v;
+      }
+    }
   }
 };
 

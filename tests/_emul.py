@@ -21,7 +21,7 @@ def build():
     src = os.path.join(HERE, "emul", "emul.cpp")
     out = os.path.join(HERE, "emul", "libodef_emul.so")
     deps = [src] + [os.path.join(ROOT, "odefilters.jl_amd", "csrc", f) for f in
-                    ("ek_math.h", "ek_lane.h", "rhs.h", "dispatch.h", "odef_platform.h", "team.h", "smooth_team.h", "filter_team.h", "smooth_rows.h", "smooth_lane.h", "dense_lane.h")]
+                    ("ek_math.h", "ek_lane.h", "rhs.h", "dispatch.h", "odef_platform.h", "team.h", "smooth_team.h", "filter_team.h", "smooth_rows.h", "smooth_lane.h", "dense_lane.h", "filter_tiles.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++20", "-shared", "-fPIC", "-Wno-unknown-pragmas", src, "-o", out])
     return out
@@ -131,7 +131,8 @@ def emul_solve(rhs_id, d, q, ek1, u0s, p, *, team=False, tgrid=None, adaptive=Fa
     smean = np.zeros_like(mean) if smooth else np.zeros(1)
     scov = np.zeros_like(cov) if smooth else np.zeros(1)
     a.smean, a.scov, a.n_save = _p(smean), _p(scov), n_save
-    rc = (lib().emul_filter_team if team else lib().emul_filter)(C.byref(a))
+    fn = lib().emul_filter_tiles if team == "tiles" else (lib().emul_filter_team if team else lib().emul_filter)
+    rc = fn(C.byref(a))
     assert rc == 0, rc
     out = dict(mean=mean.transpose(2, 0, 1), cov=unpack_tril(cov.transpose(2, 0, 1), D), diff=diff.T, tsave=tsave.T,
                loglik=loglik, naccept=ints[0], nreject=ints[1], nf=ints[2], njac=ints[3], nsaved=ints[4],

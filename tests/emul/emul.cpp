@@ -9,6 +9,7 @@
 #include "../../odefilters.jl_amd/csrc/smooth_lane.h"
 #include "../../odefilters.jl_amd/csrc/dense_lane.h"
 #include "../../odefilters.jl_amd/csrc/filter_team.h"
+#include "../../odefilters.jl_amd/csrc/filter_tiles.h"
 #include <vector>
 #include <cstring>
 
@@ -180,4 +181,23 @@ extern "C" int emul_dense(const EmulDense* e, int d) {
   if (d == 2) return dispatch_smooth_order<2>(a->q, r);
   if (d == 3) return dispatch_smooth_order<3>(a->q, r);
   return -2;
+}
+
+// register-tiled Pleiades filter (filter_tiles.h): all 320 threads emulated phase by phase
+struct RunTilesFilter {
+  const FilterParams& P;
+  template <class RHS, int q, bool EK1>
+  void operator()() {
+    using TF = TilesFilter<RHS, q, EK1>;
+    std::vector<double> sm(TF::W::size);
+    std::vector<TileState> st(kTilesThreads);
+    for (long i = 0; i < P.N; ++i) TF::run(P, i, 0, sm.data(), st.data());
+  }
+};
+extern "C" int emul_filter_tiles(const EmulArgs* a) {
+  FilterParams P;
+  fill(*a, P);
+  RunTilesFilter r{P};
+  if (a->rhs != 5) return -2;
+  return dispatch_order<RhsPleiades>(a->q, a->ek1, r);
 }

@@ -98,14 +98,15 @@ def test_team_filter_matches_lane_filter_and_oracle():
     np.testing.assert_allclose(rt["loglik"], rl["loglik"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("path", [True, "tiles"])
 @pytest.mark.parametrize("q,ek1", [(2, True), (3, False), (5, True)])
-def test_pleiades_team_filter(q, ek1):
+def test_pleiades_team_filter(q, ek1, path):
     """BASELINE config 4 problem (d = 28) through the team path: Taylor-mode init with r^-3 jets, filter, smoother."""
     vf = orc.vector_field("pleiades")
     alg = orc.Alg("EK1" if ek1 else "EK0", q, "dynamic", True)
     ns = 10
     sol = orc.solve(vf, alg, dt=2.0**-10, tspan=(0.0, ns * 2.0**-10))
-    r = E.emul_solve(vf.rhs_id, 28, q, ek1, vf.u0[None, :], vf.p, team=True, tgrid=np.array(sol.t), smooth=True)
+    r = E.emul_solve(vf.rhs_id, 28, q, ek1, vf.u0[None, :], vf.p, team=path, tgrid=np.array(sol.t), smooth=True)
     M = sol.means(smoothed=False)
     np.testing.assert_allclose(r["mean"][0][0], M[0], rtol=1e-13, atol=1e-13)  # Taylor-mode initial state
     np.testing.assert_allclose(r["mean"][0][:, :28], M[:, :28], rtol=1e-12, atol=1e-13)
