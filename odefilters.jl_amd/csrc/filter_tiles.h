@@ -13,6 +13,7 @@
 #pragma once
 #include "ek_lane.h"
 #include "team.h"
+#include "wave_vec.h"
 
 namespace odef {
 
@@ -75,6 +76,33 @@ __device__ unsigned long long g_stamp_last = 0;
     (void)S; (void)tid;                                                    \
     __VA_ARGS__                                                            \
   }                                                                        \
+  __syncthreads();
+#endif
+
+// Sections that involve at most 64 threads (Cholesky of the d x d matrix W, Householder QR of the
+// 2d x d matrix G, the serial triangular solves) run on wavefront 0 alone: their phases are separated by
+// a wave-scope fence instead of a workgroup barrier; the other wavefronts wait at the closing barrier.
+#ifdef ODEF_HOST_EMUL
+#define ODEF_TILES_WAVE0_BEGIN {
+#define ODEF_TILES_WPHASE(...)                                             \
+  for (int tid = 0; tid < 64; ++tid) {                                     \
+    TileState& S = st[tid];                                                \
+    (void)S;                                                               \
+    __VA_ARGS__                                                            \
+  }
+#define ODEF_TILES_WAVE0_END }
+#else
+#define ODEF_TILES_WAVE0_BEGIN if (tid_dev < 64) {
+#define ODEF_TILES_WPHASE(...)                                             \
+  {                                                                        \
+    const int tid = tid_dev;                                               \
+    TileState& S = st[0];                                                  \
+    (void)S; (void)tid;                                                    \
+    __VA_ARGS__                                                            \
+  }                                                                        \
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");                   \
+  __builtin_amdgcn_wave_barrier();
+#define ODEF_TILES_WAVE0_END }                                             \
   __syncthreads();
 #endif
 
@@ -183,6 +211,7 @@ struct TilesFilter {
     ODEF_STAMP(3)
     double sigma2_pred = 1.0;
     if (!fixed_diffusion) {  // sigma^2 = |Lw^-1 z|^2 / d  (src/diffusions.jl:72-80)
+#ifndef ODEF_TILES_WAVE_CHOL  // default: LDS version; the wavefront-register version (wave_vec.h) measured slower at full occupancy
       for (int k = 0; k < d; ++k) {  // right-looking Cholesky of W in LDS, one thread per row
         ODEF_TILES_PHASE(
           if (tid < d) col[tid] = WM[tid * W::LDd + k];
@@ -229,6 +258,15 @@ _Pragma("unroll")
           sc[4] = acc / d;
         }
       )
+#else
+      ODEF_TILES_WAVE0_BEGIN
+      {  // Cholesky of W and the forward substitution, in the registers of wavefront 0 (wave_vec.h)
+        const double acc = wv::chol_quadform<d>(wv::lds(WM), W::LDd, wv::lds(z));
+        wv::store_uniform(wv::lds(sc + 0), acc / d);
+        wv::store_uniform(wv::lds(sc + 4), acc / d);
+      }
+      ODEF_TILES_WAVE0_END
+#endif
       sigma2_pred = sc[0];
     }
     ODEF_STAMP(4)
@@ -251,17 +289,29 @@ _Pragma("unroll")
             const double coef = S.aj[j] * S.ak[k];
             const int rt = j * tpb + si;
             const int ct = k * tpb + sj;
-            const bool lower = rt >= ct;
-            const double* src = EX + (lower ? (rt * (rt + 1) / 2 + ct) : (ct * (ct + 1) / 2 + rt)) * T2;
-            const int sr = lower ? TS : 1;  // element (r, c) of the source tile, transposed when it is stored as (ct, rt)
-            const int scs = lower ? 1 : TS;
+            // The source tile is stored as (rt, ct) when rt >= ct and transposed as (ct, rt) otherwise.  The two
+            // cases are separate code paths so that every LDS read is base + compile-time offset.
+            auto gather = [&](auto lower_c) {
+              constexpr bool lower = decltype(lower_c)::value;
+              const double* src = EX + (lower ? (rt * (rt + 1) / 2 + ct) : (ct * (ct + 1) / 2 + rt)) * T2;
 _Pragma("unroll")
-            for (int r = 0; r < TS; ++r) {
-              double v[TS];
+              for (int r = 0; r < TS; ++r) {
+                double v[TS];
 _Pragma("unroll")
-              for (int c = 0; c < TS; ++c) v[c] = src[r * sr + c * scs];
+                for (int c = 0; c < TS; ++c) v[c] = src[lower ? r * TS + c : c * TS + r];
 _Pragma("unroll")
-              for (int c = 0; c < TS; ++c) acc[r][c] += coef * v[c];
+                for (int c = 0; c < TS; ++c) acc[r][c] += coef * v[c];
+              }
+            };
+            if constexpr (j > k) {
+              gather(std::true_type{});
+            } else if constexpr (j < k) {
+              gather(std::false_type{});
+            } else {
+              if (rt >= ct)
+                gather(std::true_type{});
+              else
+                gather(std::false_type{});
             }
           }
         });
@@ -276,53 +326,87 @@ _Pragma("unroll")
       }
     )
     ODEF_STAMP(5)
-    // Cholesky of the first 2d columns, right-looking; the tiles right of them end as the Schur complement
-    for (int kt = 0; kt < d2 / TS; ++kt) static_for<0, TS>([&](auto kcc) {
-      constexpr int kc = decltype(kcc)::value;  // column inside the tile: compile-time, so the tile stays in registers
-      const int k = kt * TS + kc;
+    // Blocked right-looking Cholesky of the first 2d columns (tile columns 0 .. 2d/TS-1); the tiles right of
+    // them end as the Schur complement.  Per tile column: (1) the diagonal tile is factored in registers,
+    // (2) the panel tiles below it are solved against it and published, (3) every trailing tile subtracts
+    // the product of its two panel tiles.  A failing pivot zeroes its column, as in the unblocked form
+    // (the reference's QR-fallback case, src/filtering.jl:38-47).
+    double* DT = col;  // TS x TS diagonal factor followed by the TS reciprocal pivots
+    for (int kt = 0; kt < d2 / TS; ++kt) {
       ODEF_TILES_PHASE(
-        if (S.I >= 0 && S.J == kt) {
-          _Pragma("unroll")
-          for (int r = 0; r < TS; ++r) {
-            const int i = S.I * TS + r;
-            if (i >= k) col[i] = S.x[r][kc];
-          }
-        }
-      )
-      ODEF_TILES_PHASE(
-        if (S.I >= 0 && S.J >= kt) {
-          const double piv = col[k];
-          const bool ok = piv > 0.0;  // failing pivot: the reference's QR-fallback case (src/filtering.jl:38-47)
-          const double inv = ok ? 1.0 / piv : 0.0;
-          // stage the 14 column entries this tile needs, zeroing those outside the trailing block
-          double ci[TS];
-          double cj[TS];
+        if (S.I == kt && S.J == kt) {
+          double invd[TS];
+          static_for<0, TS>([&](auto kcc) {
+            constexpr int kc = decltype(kcc)::value;
+            const double piv = S.x[kc][kc];
+            const bool ok = piv > 0.0;
+            const double dg = ok ? sqrt(piv) : 0.0;
+            const double rs = ok ? 1.0 / dg : 0.0;
+            invd[kc] = rs;
+            S.x[kc][kc] = dg;
 _Pragma("unroll")
-          for (int r = 0; r < TS; ++r) {
-            const int i = S.I * TS + r;
-            const int j = S.J * TS + r;
-            const double vi = col[i];
-            const double vj = col[j];
-            ci[r] = (i > k) ? vi * inv : 0.0;
-            cj[r] = (j > k) ? vj : 0.0;
-          }
+            for (int r = kc + 1; r < TS; ++r) S.x[r][kc] *= rs;
+_Pragma("unroll")
+            for (int r = kc + 1; r < TS; ++r)
+_Pragma("unroll")
+              for (int c = kc + 1; c <= r; ++c) S.x[r][c] -= S.x[r][kc] * S.x[c][kc];
+          });
 _Pragma("unroll")
           for (int r = 0; r < TS; ++r)
 _Pragma("unroll")
-            for (int c = 0; c < TS; ++c) S.x[r][c] -= ci[r] * cj[c];
-          if (S.J == kt) {
-            const double rs = ok ? 1.0 / sqrt(piv) : 0.0;
-            const double dg = ok ? sqrt(piv) : 0.0;
+            for (int c = 0; c < TS; ++c) DT[r * TS + c] = (c <= r) ? S.x[r][c] : 0.0;
 _Pragma("unroll")
-            for (int r = 0; r < TS; ++r) {
-              const int i = S.I * TS + r;
-              const double lv = col[i] * rs;
-              S.x[r][kc] = (i > k) ? lv : ((i == k) ? dg : S.x[r][kc]);
-            }
-          }
+          for (int c = 0; c < TS; ++c) DT[T2 + c] = invd[c];
         }
       )
-    });
+      ODEF_TILES_PHASE(
+        if (S.I > kt && S.J == kt) {
+          double l[TS][TS];
+          double invd[TS];
+_Pragma("unroll")
+          for (int r = 0; r < TS; ++r)
+_Pragma("unroll")
+            for (int c = 0; c < TS; ++c) l[r][c] = DT[r * TS + c];
+_Pragma("unroll")
+          for (int c = 0; c < TS; ++c) invd[c] = DT[T2 + c];
+          static_for<0, TS>([&](auto cc) {  // X <- X L^-T, column by column; the TS rows are independent
+            constexpr int c = decltype(cc)::value;
+_Pragma("unroll")
+            for (int r = 0; r < TS; ++r) {
+              double v = S.x[r][c];
+_Pragma("unroll")
+              for (int j = 0; j < c; ++j) v -= S.x[r][j] * l[c][j];
+              S.x[r][c] = v * invd[c];
+            }
+          });
+          double* dst = EX + S.I * T2;
+_Pragma("unroll")
+          for (int r = 0; r < TS; ++r)
+_Pragma("unroll")
+            for (int c = 0; c < TS; ++c) dst[r * TS + c] = S.x[r][c];
+        }
+      )
+      ODEF_TILES_PHASE(
+        if (S.I >= 0 && S.J > kt) {
+          const double* pi_ = EX + S.I * T2;
+          const double* pj_ = EX + S.J * T2;
+          static_for<0, TS>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            double a[TS];
+            double b[TS];
+_Pragma("unroll")
+            for (int r = 0; r < TS; ++r) {
+              a[r] = pi_[r * TS + k];
+              b[r] = pj_[r * TS + k];
+            }
+_Pragma("unroll")
+            for (int r = 0; r < TS; ++r)
+_Pragma("unroll")
+              for (int c = 0; c < TS; ++c) S.x[r][c] -= a[r] * b[c];
+          });
+        }
+      )
+    }
     ODEF_STAMP(6)
     // publish L1 (lower-trapezoidal D x 2d) to LDS
     ODEF_TILES_PHASE(
@@ -354,11 +438,12 @@ _Pragma("unroll")
       }
     )
     ODEF_STAMP(7)
-    // Householder QR of G: threads < 2d store the reflector, threads in (k, d) update their column
-    // One thread per ROW of G (2d threads).  Per reflector k: (A) publish column k, (B) every row thread
-    // derives the reflector scalars from the published column and publishes v_i * G[i][c], (C) thread c
-    // sums its column of partial products, (D) every row thread updates its row.  All LDS reads are
-    // issued in independent batches.
+    // Householder QR of G; reflectors, beta and R land in LDS.  Default: one thread per ROW of G (2d threads),
+    // per reflector k (A) publish column k, (B) every row thread derives the reflector scalars from the
+    // published column and publishes v_i * G[i][c], (C) thread c sums its column of partial products, (D) every
+    // row thread updates its row; all LDS reads are issued in independent batches.
+    // -DODEF_TILES_WAVE_QR: the same factorisation in the registers of wavefront 0 (wave_vec.h).
+#ifndef ODEF_TILES_WAVE_QR
     double* PB = ZP;          // 2d x LDZ partial products (region ZP is free until the row phase)
     double* sbuf = col + D;   // d column sums
     for (int k = 0; k < d; ++k) {
@@ -438,8 +523,15 @@ _Pragma("unroll")
       )
     }
     ODEF_STAMP(8)
+    ODEF_TILES_WAVE0_BEGIN
+#else
+    ODEF_TILES_WAVE0_BEGIN
+    wv::householder_qr<d>(wv::lds(G), wv::lds(HV), wv::lds(beta), wv::lds(R));
+    ODEF_TILES_WPHASE()
+    ODEF_STAMP(8)
+#endif
     // y = R^-T z ; z'S^-1 z ; log det S  (src/perform_step.jl:66)
-    ODEF_TILES_PHASE(
+    ODEF_TILES_WPHASE(
       if (tid == 0) {
         double zSz = 0.0;
         double logacc = 0.0;
@@ -463,6 +555,7 @@ _Pragma("unroll")
         }
       }
     )
+    ODEF_TILES_WAVE0_END
     ODEF_STAMP(9)
     // rows of L1 times Q (src/filtering.jl:85-89): one thread per row, the row in registers
     ODEF_TILES_PHASE(

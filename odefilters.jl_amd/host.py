@@ -19,7 +19,8 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libodefilter_hip.so")
+# ODEFILTER_HIP_LIB: development override to A/B-test another build of the same library
+LIB_PATH = os.environ.get("ODEFILTER_HIP_LIB") or os.path.join(_HERE, "lib", "libodefilter_hip.so")
 
 # ---- enums (include/odefilter.h) ---------------------------------------------------------
 EK0_ID, EK1_ID = 0, 1
