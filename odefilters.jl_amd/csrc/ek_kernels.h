@@ -97,20 +97,24 @@ __global__ __launch_bounds__(kTeamBig) void rts_smooth_team_kernel(const SmoothP
   smooth_team_lane<d, q, kTeamBig>(P, (long)blockIdx.x, (int)threadIdx.x, ws + (size_t)blockIdx.x * SmoothWs<d, q + 1>::size);
 }
 
-// Register-tiled workgroup-per-trajectory filter (filter_tiles.h): 320 threads, one 7 x 7 covariance tile each.
+// Register-tiled workgroup-per-trajectory filter (filter_tiles.h): 320 threads with one 7 x 7 covariance tile each
+// plus one helper wavefront for the small sequential factorisations.
 template <class RHS, int q, bool EK1>
-__global__ __launch_bounds__(kTilesThreads) void ek_filter_tiles_kernel(const FilterParams P) {
+__global__ __launch_bounds__(kTilesBlock) void ek_filter_tiles_kernel(const FilterParams P) {
   using TF = TilesFilter<RHS, q, EK1>;
   __shared__ double sm[TF::W::size];
   TileState st;
-  TF::run(P, (long)blockIdx.x, (int)threadIdx.x, sm, &st);
+  if (threadIdx.x >= kTilesThreads)  // the helper wavefront: same barriers, its own code path
+    TF::template run<true>(P, (long)blockIdx.x, (int)threadIdx.x, sm, &st);
+  else
+    TF::template run<false>(P, (long)blockIdx.x, (int)threadIdx.x, sm, &st);
 }
 struct LaunchTilesFilter {
   const FilterParams& P;
   hipStream_t s;
   template <class RHS, int q, bool EK1>
   void operator()() {
-    hipLaunchKernelGGL((ek_filter_tiles_kernel<RHS, q, EK1>), dim3((unsigned)P.N), dim3(kTilesThreads), 0, s, P);
+    hipLaunchKernelGGL((ek_filter_tiles_kernel<RHS, q, EK1>), dim3((unsigned)P.N), dim3(kTilesBlock), 0, s, P);
   }
 };
 

@@ -18,7 +18,8 @@
 namespace odef {
 
 constexpr int kTile = 7;
-constexpr int kTilesThreads = 320;
+constexpr int kTilesThreads = 320;              // tile threads
+constexpr int kTilesBlock = kTilesThreads + 64;  // + one helper wavefront (see ODEF_TILES_HELPER)
 
 template <int d, int NB>
 struct TilesLds {
@@ -61,6 +62,15 @@ __device__ unsigned long long g_stamp_last = 0;
 #define ODEF_STAMP(k)
 #endif
 
+// Wave specialisation.  The workgroup has kTilesThreads tile threads plus ONE helper wavefront that owns no
+// tile.  step() and run() are compiled twice (template parameter HELPER) from the same source:
+//   ODEF_TILES_PHASE(body)   tile threads run body; everybody (helper included) meets at the closing barrier,
+//                            so both instantiations execute the same number of barriers by construction;
+//   ODEF_TILES_HELPER(body)  only the helper wavefront runs body (written in the one-value-per-lane form of
+//                            wave_vec.h, no barrier inside); the tile threads walk on to the next barrier.
+// The small sequential factorisations (Cholesky of W, Householder QR of G, the triangular solves) live in helper
+// sections: ~150 live registers that never meet the 7 x 7 tile a tile thread carries, and the Cholesky of W
+// overlaps with the congruence.  Host emulation: one instantiation, helper sections run in line.
 #ifdef ODEF_HOST_EMUL
 #define ODEF_TILES_PHASE(...)                                              \
   for (int tid = 0; tid < kTilesThreads; ++tid) {                          \
@@ -68,42 +78,17 @@ __device__ unsigned long long g_stamp_last = 0;
     (void)S;                                                               \
     __VA_ARGS__                                                            \
   }
+#define ODEF_TILES_HELPER(...) { __VA_ARGS__ }
 #else
 #define ODEF_TILES_PHASE(...)                                              \
-  {                                                                        \
+  if constexpr (!HELPER) {                                                 \
     const int tid = tid_dev;                                               \
     TileState& S = st[0];                                                  \
     (void)S; (void)tid;                                                    \
     __VA_ARGS__                                                            \
   }                                                                        \
   __syncthreads();
-#endif
-
-// Sections that involve at most 64 threads (Cholesky of the d x d matrix W, Householder QR of the
-// 2d x d matrix G, the serial triangular solves) run on wavefront 0 alone: their phases are separated by
-// a wave-scope fence instead of a workgroup barrier; the other wavefronts wait at the closing barrier.
-#ifdef ODEF_HOST_EMUL
-#define ODEF_TILES_WAVE0_BEGIN {
-#define ODEF_TILES_WPHASE(...)                                             \
-  for (int tid = 0; tid < 64; ++tid) {                                     \
-    TileState& S = st[tid];                                                \
-    (void)S;                                                               \
-    __VA_ARGS__                                                            \
-  }
-#define ODEF_TILES_WAVE0_END }
-#else
-#define ODEF_TILES_WAVE0_BEGIN if (tid_dev < 64) {
-#define ODEF_TILES_WPHASE(...)                                             \
-  {                                                                        \
-    const int tid = tid_dev;                                               \
-    TileState& S = st[0];                                                  \
-    (void)S; (void)tid;                                                    \
-    __VA_ARGS__                                                            \
-  }                                                                        \
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");                   \
-  __builtin_amdgcn_wave_barrier();
-#define ODEF_TILES_WAVE0_END }                                             \
-  __syncthreads();
+#define ODEF_TILES_HELPER(...) if constexpr (HELPER) { __VA_ARGS__ }
 #endif
 
 template <class RHS, int q, bool IS_EK1>
@@ -112,6 +97,7 @@ struct TilesFilter {
   using W = TilesLds<d, NB>;
   static constexpr int NT = kTilesThreads, TS = kTile, T2 = TS * TS, tpb = d / TS;  // tiles per derivative block
 
+  template <bool HELPER>
   __device__ static inline void step(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab,
                                      bool fixed_diffusion, int success_iter, double* __restrict__ sm, TileState* st,
                                      int tid_dev) {
@@ -122,7 +108,6 @@ struct TilesFilter {
     double* WM = sm + W::WM;
     double* M0 = sm + W::M0;
     double* HV = sm + W::HV;
-    double* R = sm + W::R;
     double* G = sm + W::G;
     double* H0 = sm + W::H0;
     double* m = sm + W::MV;
@@ -209,68 +194,18 @@ struct TilesFilter {
       }
     )
     ODEF_STAMP(3)
-    double sigma2_pred = 1.0;
-    if (!fixed_diffusion) {  // sigma^2 = |Lw^-1 z|^2 / d  (src/diffusions.jl:72-80)
-#ifndef ODEF_TILES_WAVE_CHOL  // default: LDS version; the wavefront-register version (wave_vec.h) measured slower at full occupancy
-      for (int k = 0; k < d; ++k) {  // right-looking Cholesky of W in LDS, one thread per row
-        ODEF_TILES_PHASE(
-          if (tid < d) col[tid] = WM[tid * W::LDd + k];
-        )
-        ODEF_TILES_PHASE(
-          if (tid < d && tid >= k) {
-            const double piv = col[k];
-            const bool ok = piv > 0.0;
-            const double inv = ok ? 1.0 / piv : 0.0;
-            const double ci = col[tid] * inv;
-            double* row = WM + tid * W::LDd;
-            static_for<0, d / 7>([&](auto bb) {  // batches of 7 independent LDS reads
-              constexpr int j0 = decltype(bb)::value * 7;
-              double cj[7];
-              double w[7];
-_Pragma("unroll")
-              for (int jj = 0; jj < 7; ++jj) {
-                cj[jj] = col[j0 + jj];
-                w[jj] = row[j0 + jj];
-              }
-_Pragma("unroll")
-              for (int jj = 0; jj < 7; ++jj) {
-                const int j = j0 + jj;
-                if (j > k && j <= tid && tid > k) row[j] = w[jj] - ci * cj[jj];
-              }
-            });
-            row[k] = (tid > k) ? col[tid] * (ok ? 1.0 / sqrt(piv) : 0.0) : (ok ? sqrt(piv) : 0.0);
-          }
-        )
-      }
-      ODEF_TILES_PHASE(
-        if (tid == 0) {  // forward substitution with the solution kept in registers (independent LDS reads)
-          double yv[d];
-          double acc = 0.0;
-          static_for<0, d>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            double s = z[r];
-_Pragma("unroll")
-            for (int c = 0; c < r; ++c) s -= WM[r * W::LDd + c] * yv[c];
-            yv[r] = s / WM[r * W::LDd + r];
-            acc += yv[r] * yv[r];
-          });
-          sc[0] = acc / d;
-          sc[4] = acc / d;
-        }
-      )
-#else
-      ODEF_TILES_WAVE0_BEGIN
-      {  // Cholesky of W and the forward substitution, in the registers of wavefront 0 (wave_vec.h)
+    // sigma^2 = z' W^-1 z / d (src/diffusions.jl:72-80): Cholesky of W and the forward substitution in the
+    // registers of the helper wavefront, CONCURRENT with the congruence of the tile threads below; the value is
+    // picked up after the congruence's closing barrier (first phase of the Cholesky).
+    if (!fixed_diffusion) {
+      ODEF_TILES_HELPER(
         const double acc = wv::chol_quadform<d>(wv::lds(WM), W::LDd, wv::lds(z));
         wv::store_uniform(wv::lds(sc + 0), acc / d);
         wv::store_uniform(wv::lds(sc + 4), acc / d);
-      }
-      ODEF_TILES_WAVE0_END
-#endif
-      sigma2_pred = sc[0];
+      )
     }
     ODEF_STAMP(4)
-    // predict_cov! (src/filtering.jl:33-41): own tile of A S A' + sigma2 Q from the published tiles
+    // predict_cov! (src/filtering.jl:33-41): own tile of A S A' from the published tiles (sigma2 Q is added below)
     ODEF_TILES_PHASE(
       if (S.I >= 0) {
         const int Jb = S.I / tpb;
@@ -315,10 +250,6 @@ _Pragma("unroll")
             }
           }
         });
-        if (si == sj) {
-_Pragma("unroll")
-          for (int r = 0; r < TS; ++r) acc[r][r] += sigma2_pred * S.qjk;
-        }
 _Pragma("unroll")
         for (int r = 0; r < TS; ++r)
 _Pragma("unroll")
@@ -334,6 +265,11 @@ _Pragma("unroll")
     double* DT = col;  // TS x TS diagonal factor followed by the TS reciprocal pivots
     for (int kt = 0; kt < d2 / TS; ++kt) {
       ODEF_TILES_PHASE(
+        if (kt == 0 && S.I >= 0 && (S.I % tpb) == (S.J % tpb)) {  // + sigma2 Q: the helper's sigma2 is ready now
+          const double sigma2_pred = fixed_diffusion ? 1.0 : sc[0];
+_Pragma("unroll")
+          for (int r = 0; r < TS; ++r) S.x[r][r] += sigma2_pred * S.qjk;
+        }
         if (S.I == kt && S.J == kt) {
           double invd[TS];
           static_for<0, TS>([&](auto kcc) {
@@ -438,124 +374,22 @@ _Pragma("unroll")
       }
     )
     ODEF_STAMP(7)
-    // Householder QR of G; reflectors, beta and R land in LDS.  Default: one thread per ROW of G (2d threads),
-    // per reflector k (A) publish column k, (B) every row thread derives the reflector scalars from the
-    // published column and publishes v_i * G[i][c], (C) thread c sums its column of partial products, (D) every
-    // row thread updates its row; all LDS reads are issued in independent batches.
-    // -DODEF_TILES_WAVE_QR: the same factorisation in the registers of wavefront 0 (wave_vec.h).
-#ifndef ODEF_TILES_WAVE_QR
-    double* PB = ZP;          // 2d x LDZ partial products (region ZP is free until the row phase)
-    double* sbuf = col + D;   // d column sums
-    for (int k = 0; k < d; ++k) {
-      ODEF_TILES_PHASE(
-        if (tid < d2) col[tid] = (tid >= k) ? G[tid * d + k] : 0.0;
-      )
-      ODEF_TILES_PHASE(
-        if (tid < d2) {
-          double nrm2 = 0.0;
-          static_for<0, d2 / 7>([&](auto bb) {
-            constexpr int i0 = decltype(bb)::value * 7;
-            double v[7];
-_Pragma("unroll")
-            for (int ii = 0; ii < 7; ++ii) v[ii] = col[i0 + ii];
-_Pragma("unroll")
-            for (int ii = 0; ii < 7; ++ii) nrm2 += v[ii] * v[ii];
-          });
-          const double nrm = sqrt(nrm2);
-          const double x0 = col[k];
-          const double alpha = (x0 >= 0.0) ? -nrm : nrm;
-          const double v0 = x0 - alpha;
-          const double vtv = nrm2 - x0 * x0 + v0 * v0;
-          const double bt = (vtv > 0.0) ? 2.0 / vtv : 0.0;
-          const double vi = (tid == k) ? v0 : col[tid];  // zero for rows above k
-          if (tid >= k) HV[k * d2 + tid] = vi;
-          if (tid == 0) {
-            beta[k] = bt;
-            R[k * d + k] = alpha;
-          }
-          static_for<0, d / 7>([&](auto bb) {
-            constexpr int c0 = decltype(bb)::value * 7;
-            double g[7];
-_Pragma("unroll")
-            for (int cc = 0; cc < 7; ++cc) g[cc] = G[tid * d + c0 + cc];
-_Pragma("unroll")
-            for (int cc = 0; cc < 7; ++cc) PB[tid * W::LDZ + c0 + cc] = vi * g[cc];
-          });
-        }
-      )
-      ODEF_TILES_PHASE(
-        if (tid < d) {
-          double sacc = 0.0;
-          static_for<0, d2 / 7>([&](auto bb) {
-            constexpr int i0 = decltype(bb)::value * 7;
-            double v[7];
-_Pragma("unroll")
-            for (int ii = 0; ii < 7; ++ii) v[ii] = PB[(i0 + ii) * W::LDZ + tid];
-_Pragma("unroll")
-            for (int ii = 0; ii < 7; ++ii) sacc += v[ii];
-          });
-          sbuf[tid] = sacc * beta[k];
-        }
-      )
-      ODEF_TILES_PHASE(
-        if (tid < d2 && tid >= k) {
-          const double vi = (tid == k) ? HV[k * d2 + k] : col[tid];
-          static_for<0, d / 7>([&](auto bb) {
-            constexpr int c0 = decltype(bb)::value * 7;
-            double g[7];
-            double sv[7];
-_Pragma("unroll")
-            for (int cc = 0; cc < 7; ++cc) {
-              g[cc] = G[tid * d + c0 + cc];
-              sv[cc] = sbuf[c0 + cc];
-            }
-_Pragma("unroll")
-            for (int cc = 0; cc < 7; ++cc) {
-              const int c = c0 + cc;
-              if (c > k) {
-                const double gn = g[cc] - sv[cc] * vi;
-                G[tid * d + c] = gn;
-                if (tid == k) R[k * d + c] = gn;
-              }
-            }
-          });
-        }
-      )
-    }
-    ODEF_STAMP(8)
-    ODEF_TILES_WAVE0_BEGIN
-#else
-    ODEF_TILES_WAVE0_BEGIN
-    wv::householder_qr<d>(wv::lds(G), wv::lds(HV), wv::lds(beta), wv::lds(R));
-    ODEF_TILES_WPHASE()
-    ODEF_STAMP(8)
-#endif
-    // y = R^-T z ; z'S^-1 z ; log det S  (src/perform_step.jl:66)
-    ODEF_TILES_WPHASE(
-      if (tid == 0) {
-        double zSz = 0.0;
-        double logacc = 0.0;
-        double yv[d];
-        static_for<0, d>([&](auto rc) {
-          constexpr int r = decltype(rc)::value;
-          double s = z[r];
-_Pragma("unroll")
-          for (int c = 0; c < r; ++c) s -= R[c * d + r] * yv[c];
-          yv[r] = s / R[r * d + r];
-          y[r] = yv[r];
-          zSz += yv[r] * yv[r];
-          logacc += log(fabs(R[r * d + r]));
-        });
-        sc[1] = zSz;
-        sc[3] += -0.5 * (zSz + 2.0 * logacc + d * 1.8378770664093453);
-        if (fixed_diffusion) {  // src/diffusions.jl:11-36
-          const double dt_ = zSz / d;
-          sc[0] = dt_;
-          sc[4] = (success_iter == 0) ? dt_ : sc[4] + (dt_ - sc[4]) / success_iter;
-        }
+    // Householder QR of G, y = R^-T z, z'S^-1 z and log det S (src/perform_step.jl:66) in the registers of the
+    // helper wavefront (wave_vec.h); the reflectors, beta and y land in LDS, R never leaves the registers.
+    ODEF_TILES_HELPER(
+      double zSz;
+      double logacc;
+      wv::householder_qr_solve<d>(wv::lds(G), wv::lds(z), wv::lds(HV), wv::lds(beta), wv::lds(y), zSz, logacc);
+      wv::store_uniform(wv::lds(sc + 1), zSz);
+      wv::store_uniform(wv::lds(sc + 3), wv::load_uniform(wv::lds(sc + 3)) - 0.5 * (zSz + 2.0 * logacc + d * 1.8378770664093453));
+      if (fixed_diffusion) {  // src/diffusions.jl:11-36
+        const double dt_ = zSz / d;
+        const double prev = wv::load_uniform(wv::lds(sc + 4));
+        wv::store_uniform(wv::lds(sc + 0), dt_);
+        wv::store_uniform(wv::lds(sc + 4), (success_iter == 0) ? dt_ : prev + (dt_ - prev) / success_iter);
       }
     )
-    ODEF_TILES_WAVE0_END
+    ODEF_TILES_PHASE()  // the tile threads wait here for the helper
     ODEF_STAMP(9)
     // rows of L1 times Q (src/filtering.jl:85-89): one thread per row, the row in registers
     ODEF_TILES_PHASE(
@@ -616,6 +450,7 @@ _Pragma("unroll")
   }
 
   // whole fixed-step solve of trajectory i.  `st`: one TileState (device) / kTilesThreads of them (host).
+  template <bool HELPER>
   __device__ static inline void run(const FilterParams& P, long i, int tid_dev, double* __restrict__ sm, TileState* st) {
     double* m = sm + W::MV;
     double* sc = sm + W::SC;
@@ -678,7 +513,7 @@ _Pragma("unroll")
     if (P.everystep) save(0);
     for (long n = 0; n < P.nsteps; ++n) {
       const double* tab = P.ptab + (size_t)P.tab_idx[n] * kTabStride;
-      step(P.pc, pl, tab, P.fixed_diffusion != 0, (int)n, sm, st, tid_dev);
+      step<HELPER>(P.pc, pl, tab, P.fixed_diffusion != 0, (int)n, sm, st, tid_dev);
       if (P.everystep) save(n + 1);
     }
     if (!P.everystep) save(0);

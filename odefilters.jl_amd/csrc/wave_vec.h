@@ -110,10 +110,26 @@ inline void store(double* p, int stride, const WB& mask, const WD& x) {
 }
 inline void store_from_lane(double* p, int lane, const WD& x) { *p = x.v[lane]; }
 inline void store_uniform(double* p, double x) { *p = x; }
+inline double load_uniform(const double* p) { return *p; }
+inline WD wlog(const WD& a) {
+  WD r;
+  for (int l = 0; l < kLanes; ++l) r.v[l] = std::log(a.v[l]);
+  return r;
+}
+inline WD wabs(const WD& a) {
+  WD r;
+  for (int l = 0; l < kLanes; ++l) r.v[l] = std::fabs(a.v[l]);
+  return r;
+}
+inline WD wrcp(const WD& a) {
+  WD r;
+  for (int l = 0; l < kLanes; ++l) r.v[l] = 1.0 / a.v[l];
+  return r;
+}
 #else
 using WD = double;
 using WB = bool;
-__device__ inline int lane_id() { return (int)threadIdx.x; }  // wavefront 0 of the workgroup
+__device__ inline int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ inline WD splat(double a) { return a; }
 __device__ inline WD select(WB c, WD a, WD b) { return c ? a : b; }
 __device__ inline WB lane_ge(int k) { return lane_id() >= k; }
@@ -141,6 +157,10 @@ __device__ inline void store_from_lane(LdsP p, int lane, WD x) {
 __device__ inline void store_uniform(LdsP p, double x) {
   if (lane_id() == 0) *p = x;
 }
+__device__ inline double load_uniform(LdsCP p) { return *p; }
+__device__ inline WD wlog(WD a) { return log(a); }
+__device__ inline WD wabs(WD a) { return fabs(a); }
+__device__ inline WD wrcp(WD a) { return 1.0 / a; }
 #endif
 
 // Sum over the 64 lanes of P values each (P a power of two <= 32) by a reduce-scatter butterfly:
@@ -210,10 +230,11 @@ constexpr int next_pow2(int n) { return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : n
 
 // Householder QR of the 2d x d matrix G (LDS, row-major): row i in the registers of lane i.  Per reflector
 // ONE reduce-scatter butterfly yields x'x and x'g_c for all remaining columns; v'g_c follows from
-// v = x - alpha e_k.  Outputs (LDS): the reflectors HV[k][k..2d), beta[k], and the rows of R (row k is final
-// once reflector k has been applied, so R, its diagonal and beta are stored once at the end).
+// v = x - alpha e_k.  Row k of R is final once reflector k has been applied and stays in lane k, so the
+// forward substitution y = R^-T z, z'S^-1 z = |y|^2 and log det S = 2 sum log|R_kk| follow without touching LDS.
+// Outputs (LDS): the reflectors HV[k][k..2d), beta[0..d), y[0..d).  R itself is stored only when R_out != null.
 template <int d>
-ODEF_WV_FN void householder_qr(LdsCP G, LdsP HV, LdsP beta, LdsP R) {
+ODEF_WV_FN void householder_qr_solve(LdsCP G, LdsCP z, LdsP HV, LdsP beta, LdsP y, double& zSz, double& logacc, LdsP R_out = LdsP()) {
   constexpr int d2 = 2 * d;
   static_assert(d2 <= kLanes && d <= 32, "one lane per row of G");
   WD g[d];
@@ -257,11 +278,37 @@ ODEF_WV_FN void householder_qr(LdsCP G, LdsP HV, LdsP beta, LdsP R) {
     });
   });
   store(beta, 1, lane_range(0, d), bet);
-  store(R, d + 1, lane_range(0, d), diag);
-  static_for<1, d>([&](auto cc) {
-    constexpr int c = decltype(cc)::value;
-    store(R + c, d, lane_range(0, c), g[c]);  // R[lane][c] for lane < c
+  if (R_out) {
+    store(R_out, d + 1, lane_range(0, d), diag);
+    static_for<1, d>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      store(R_out + c, d, lane_range(0, c), g[c]);  // R[lane][c] for lane < c
+    });
+  }
+  // y = R^-T z, column-oriented: R'[r][c] = R[c][r] = g[r] of lane c; the residuals are wave-uniform values
+  const WD rinv = wrcp(select(lane_range(0, d), diag, 1.0));
+  double res[d];
+  static_for<0, d>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    res[r] = load_uniform(z + r);
   });
+  WD yv = splat(0.0);
+  zSz = 0.0;
+  static_for<0, d>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    const double yc = res[c] * bcast(rinv, c);
+    yv = select(lane_eq(c), yc, yv);
+    zSz += yc * yc;
+    static_for<c + 1, d>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      res[r] -= bcast(g[r], c) * yc;
+    });
+  });
+  store(y, 1, lane_range(0, d), yv);
+  WD lg[1];
+  lg[0] = select(lane_range(0, d), wlog(wabs(select(lane_range(0, d), diag, 1.0))), 0.0);
+  MultiSum<1>::run(lg);
+  logacc = bcast(lg[0], 0);
 }
 
 }  // namespace wv

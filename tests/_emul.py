@@ -21,7 +21,7 @@ def build():
     src = os.path.join(HERE, "emul", "emul.cpp")
     out = os.path.join(HERE, "emul", "libodef_emul.so")
     deps = [src] + [os.path.join(ROOT, "odefilters.jl_amd", "csrc", f) for f in
-                    ("ek_math.h", "ek_lane.h", "rhs.h", "dispatch.h", "odef_platform.h", "team.h", "smooth_team.h", "filter_team.h", "smooth_rows.h", "smooth_lane.h", "dense_lane.h", "filter_tiles.h")]
+                    ("ek_math.h", "ek_lane.h", "rhs.h", "dispatch.h", "odef_platform.h", "team.h", "smooth_team.h", "filter_team.h", "smooth_rows.h", "smooth_lane.h", "dense_lane.h", "filter_tiles.h", "wave_vec.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++20", "-shared", "-fPIC", "-Wno-unknown-pragmas", src, "-o", out])
     return out

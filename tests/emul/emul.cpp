@@ -183,7 +183,7 @@ extern "C" int emul_dense(const EmulDense* e, int d) {
   return -2;
 }
 
-// register-tiled Pleiades filter (filter_tiles.h): all 320 threads emulated phase by phase
+// register-tiled Pleiades filter (filter_tiles.h): all 320 tile threads emulated phase by phase, helper sections in line
 struct RunTilesFilter {
   const FilterParams& P;
   template <class RHS, int q, bool EK1>
@@ -191,7 +191,7 @@ struct RunTilesFilter {
     using TF = TilesFilter<RHS, q, EK1>;
     std::vector<double> sm(TF::W::size);
     std::vector<TileState> st(kTilesThreads);
-    for (long i = 0; i < P.N; ++i) TF::run(P, i, 0, sm.data(), st.data());
+    for (long i = 0; i < P.N; ++i) TF::template run<false>(P, i, 0, sm.data(), st.data());
   }
 };
 extern "C" int emul_filter_tiles(const EmulArgs* a) {

@@ -44,7 +44,7 @@ int main() {
   P.u0 = du0; P.p = nullptr; P.p_shared = 1; P.N = N; P.ptab = dtab; P.tab_idx = didx; P.hs = dhs; P.nsteps = nsteps; P.everystep = 0; P.want_loglik = 1;
   P.mean = dmean; P.cov = dcov; P.diff = ddiff; P.loglik = dll; P.naccept = di5; P.nreject = di5 + N; P.nf = di5 + 2 * N; P.njac = di5 + 3 * N; P.nsaved = di5 + 4 * N; P.retcode = di5 + 5 * N;
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dst, sizeof(dst)));
-  hipLaunchKernelGGL((ek_filter_tiles_kernel<RhsPleiades, q, true>), dim3((unsigned)N), dim3(kTilesThreads), 0, 0, P);
+  hipLaunchKernelGGL((ek_filter_tiles_kernel<RhsPleiades, q, true>), dim3((unsigned)N), dim3(kTilesBlock), 0, 0, P);
   CK(hipDeviceSynchronize());
   unsigned long long st[16]; CK(hipMemcpy(st, dst, sizeof st, hipMemcpyDeviceToHost));
   const char* names[12] = {"(between steps / save)", "precondition + mean", "measure (f, J by one thread)", "z, H0, M0, W", "chol(W) + sigma2", "congruence A S A'",
