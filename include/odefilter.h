@@ -23,6 +23,7 @@
  *   odef_smooth                     postamble! -> smooth_all! -> smooth!         src/integrator_utils.jl:2-30,
  *                                                                                src/smoothing.jl:4-63
  *   odef_dense_output               sol(t), GaussianODEFilterPosterior            src/solution.jl:165-214
+ *   odef_sample                     sample_states / sample                        src/solution_sampling.jl:15-62
  *   odef_get / odef_get_device      sol.t, sol.x_filt, sol.x_smooth, sol.diffusions, sol.log_likelihood,
  *                                   sol.destats, sol.retcode                     src/solution.jl:8-24
  *   odef_predict / odef_update /
@@ -99,6 +100,7 @@ typedef enum {
   ODEF_F_U0 = 13,              /* [d][N] initial values as held on the device */
   ODEF_F_DENSE_MEAN = 14,      /* [n_q][D][N]   result of odef_dense_output */
   ODEF_F_DENSE_COV_TRIL = 15,  /* [n_q][TRI][N] */
+  ODEF_F_SAMPLES = 16,         /* [n_save][D][n_samples][N] result of odef_sample */
   ODEF_F_COUNT_
 } odef_field;
 
@@ -159,6 +161,14 @@ int odef_smooth(odef_ctx* ctx);
  * (smoothed != 0: the smoothed posterior, needs odef_smooth first).  Results in ODEF_F_DENSE_MEAN /
  * ODEF_F_DENSE_COV_TRIL.  Times before t0 give NaN records (the reference throws).  State dimension <= 12. */
 int odef_dense_output(odef_ctx* ctx, const double* tq, int64_t n_q, int smoothed);
+
+/* Posterior sampling on the saved grid (src/solution_sampling.jl:24-62): n_samples joint draws of the whole state
+ * path per trajectory, x_N ~ N(mu_N, S_N) and backwards x_i ~ smooth(x_filt[i], delta(x_{i+1})).  Needs
+ * ODEF_SAVE_EVERYSTEP (the reference asserts a smoothing solve, :16); odef_smooth itself is not required.
+ * The N(0,1) stream is counter-based and reproducible from `seed` (splitmix64 + Box-Muller, see
+ * oracle/odefilter_oracle.py sample_normal); noise_scale = 1 gives samples, 0 the chain of conditional means.
+ * Result in ODEF_F_SAMPLES; sample(sol, n) of the reference is its rows 0..d-1.  State dimension <= 12. */
+int odef_sample(odef_ctx* ctx, int64_t n_samples, uint64_t seed, double noise_scale);
 
 int64_t odef_n_save(const odef_ctx* ctx); /* leading dimension of MEAN/COV_TRIL/DIFFUSION/T */
 int odef_field_bytes(const odef_ctx* ctx, int field, size_t* bytes);

@@ -53,6 +53,7 @@ struct odef_ctx {
   double* d_tq = nullptr;
   size_t tq_cap = 0;
   long n_q = 0;
+  long n_samples = 0;
   bool smoothed_done = false;
   double* d_ptab = nullptr;
   int* d_tab_idx = nullptr;
@@ -143,6 +144,7 @@ size_t field_count(const odef_ctx* c, int field, long n_save) {
     case ODEF_F_U0: return (size_t)c->d * N;
     case ODEF_F_DENSE_MEAN: return (size_t)c->n_q * c->D * N;
     case ODEF_F_DENSE_COV_TRIL: return (size_t)c->n_q * c->TRI * N;
+    case ODEF_F_SAMPLES: return (size_t)n_save * c->D * (size_t)c->n_samples * N;
     default: return N;
   }
 }
@@ -634,6 +636,41 @@ int odef_dense_output(odef_ctx* c, const double* tq, int64_t n_q, int smoothed) 
   P.qcov = (double*)c->f[ODEF_F_DENSE_COV_TRIL].ptr;
   const int rc = c->d == 2 ? launch_dense_d2(c->q, P, c->stream) : c->d == 3 ? launch_dense_d3(c->q, P, c->stream) : -3;
   if (rc) return fail(c, "odef_dense_output: no kernel for d %d order %d", c->d, c->q);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int odef_sample(odef_ctx* c, int64_t n_samples, uint64_t seed, double noise_scale) {
+  if (!c) return -1;
+  if (!c->solved) return fail(c, "odef_sample: call odef_solve_* first");
+  if (c->cfg.save_mode != ODEF_SAVE_EVERYSTEP) return fail(c, "odef_sample: needs ODEF_SAVE_EVERYSTEP (sampling not implemented for non-smoothed posteriors)");
+  if (n_samples < 1 || n_samples > 65535) return fail(c, "odef_sample: n_samples must be in 1..65535");
+  if (c->team_path || c->D > 12) return fail(c, "odef_sample: built for state dimension <= 12 (got %d)", c->D);
+  if (set_device(c)) return -1;
+  c->n_samples = (long)n_samples;
+  if (ensure(c, ODEF_F_SAMPLES, field_count(c, ODEF_F_SAMPLES, c->n_save) * sizeof(double))) return -1;
+  SampleParams S;
+  std::memset(&S, 0, sizeof S);
+  S.pc = c->pc;
+  S.N = c->cfg.n_traj;
+  S.n_save = c->n_save;
+  S.adaptive = c->adaptive;
+  S.hs = c->d_hs;
+  S.ptab = c->d_ptab;
+  S.tab_idx = c->d_tab_idx;
+  S.tsave = (const double*)c->f[ODEF_F_T].ptr;
+  S.nsaved = (const int*)c->f[ODEF_F_NSAVED].ptr;
+  S.mean = (const double*)c->f[ODEF_F_MEAN].ptr;
+  S.cov = (const double*)c->f[ODEF_F_COV_TRIL].ptr;
+  S.diff = (const double*)c->f[ODEF_F_DIFFUSION].ptr;
+  S.n_samples = (long)n_samples;
+  S.seed = (unsigned long long)seed;
+  S.noise_scale = noise_scale;
+  S.samples = (double*)c->f[ODEF_F_SAMPLES].ptr;
+  if (c->adaptive) HIPCHK(c, hipMemsetAsync(S.samples, 0, c->f[ODEF_F_SAMPLES].valid, c->stream));  // unused slots stay defined
+  const int rc = c->d == 2 ? launch_sample_d2(c->q, S, c->stream) : c->d == 3 ? launch_sample_d3(c->q, S, c->stream) : -3;
+  if (rc) return fail(c, "odef_sample: no kernel for d %d order %d", c->d, c->q);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;

@@ -8,6 +8,7 @@
 #include "smooth_rows.h"
 #include "smooth_lane.h"
 #include "dense_lane.h"
+#include "sample_lane.h"
 #include "filter_team.h"
 #include "filter_tiles.h"
 #include "launch.h"
@@ -77,6 +78,30 @@ struct LaunchDense {
     if constexpr (d * (q + 1) <= kSmoothLaneMaxD) {
       dim3 grid((unsigned)((P.N + kWave - 1) / kWave), (unsigned)P.n_q);
       hipLaunchKernelGGL((dense_output_kernel<d, q>), grid, dim3(kWave), 0, s, P);
+    } else {
+      rc = -3;
+    }
+  }
+};
+
+// Posterior sampling (sample_lane.h): one lane per (trajectory, sample); blockIdx.y = sample.
+template <int d, int q>
+__global__ __launch_bounds__(kWave) void sample_kernel(const SampleParams P) {
+  constexpr int D = d * (q + 1), TRI = D * (D + 1) / 2;
+  __shared__ double lds[TRI * kWave];
+  const long i = (long)blockIdx.x * kWave + threadIdx.x;
+  const LaneMem xl{lds + threadIdx.x, kWave};
+  if (i < P.N) sample_lane<d, q>(P, i, (long)blockIdx.y, xl);
+}
+struct LaunchSample {
+  const SampleParams& P;
+  hipStream_t s;
+  int rc = 0;
+  template <int d, int q>
+  void operator()() {
+    if constexpr (d * (q + 1) <= kSmoothLaneMaxD) {
+      const dim3 grid((unsigned)((P.N + kWave - 1) / kWave), (unsigned)P.n_samples);
+      hipLaunchKernelGGL((sample_kernel<d, q>), grid, dim3(kWave), 0, s, P);
     } else {
       rc = -3;
     }

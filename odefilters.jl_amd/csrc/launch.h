@@ -5,6 +5,7 @@
 #include "filter_team.h"
 #include "team.h"
 #include "dense_lane.h"
+#include "sample_lane.h"
 
 namespace odef {
 // returns 0, or -2 when (rhs, q) is not instantiated
@@ -21,6 +22,8 @@ int launch_smooth_d3(int q, const SmoothParams& P, hipStream_t s);
 // returns -3 when the state dimension is outside the dense-output kernel's range (D <= 12)
 int launch_dense_d2(int q, const DenseParams& P, hipStream_t s);
 int launch_dense_d3(int q, const DenseParams& P, hipStream_t s);
+int launch_sample_d2(int q, const SampleParams& P, hipStream_t s);
+int launch_sample_d3(int q, const SampleParams& P, hipStream_t s);
 // workgroup-per-trajectory path (Pleiades, d = 28)
 int launch_filter_pleiades(int q, int ek1, const TeamFilterParams& TP, hipStream_t s);        // global-workspace team kernel
 int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s);     // register-tiled kernel (default)

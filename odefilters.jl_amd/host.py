@@ -31,7 +31,7 @@ RHS_DIMS = {"fhn": (2, 3), "lorenz63": (3, 3), "lotka_volterra": (2, 4), "vander
 SAVE_FINAL, SAVE_EVERYSTEP = 0, 1
 RETCODES = {0: "Success", 1: "MaxIters", 2: "DtLessThanMin", 3: "Unstable", 4: "Unstable"}
 (F_MEAN, F_COV_TRIL, F_DIFFUSION, F_T, F_LOGLIK, F_NACCEPT, F_NREJECT, F_NF, F_NJAC, F_NSAVED, F_RETCODE,
- F_SMOOTH_MEAN, F_SMOOTH_COV_TRIL, F_U0, F_DENSE_MEAN, F_DENSE_COV_TRIL) = range(16)
+ F_SMOOTH_MEAN, F_SMOOTH_COV_TRIL, F_U0, F_DENSE_MEAN, F_DENSE_COV_TRIL, F_SAMPLES) = range(17)
 _INT_FIELDS = {F_NACCEPT, F_NREJECT, F_NF, F_NJAC, F_NSAVED, F_RETCODE}
 MAX_ORDER = 5
 
@@ -66,6 +66,7 @@ SYMBOLS = {
     "odef_solve_adaptive": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(OdefController), C.c_int64]),
     "odef_smooth": (C.c_int, [_vp]),
     "odef_dense_output": (C.c_int, [_vp, _dp, C.c_int64, C.c_int]),
+    "odef_sample": (C.c_int, [_vp, C.c_int64, C.c_uint64, C.c_double]),
     "odef_n_save": (C.c_int64, [_vp]),
     "odef_field_bytes": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_size_t)]),
     "odef_get": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
@@ -205,6 +206,14 @@ class Context:
         c = np.empty(nb // 8)
         self._chk(self.lib.odef_get(self._h, F_DENSE_COV_TRIL, c.ctypes.data_as(_vp), nb))
         return m.reshape(len(tq), self.D, self.N), c.reshape(len(tq), self.TRI, self.N)
+
+    def sample_states(self, n: int, seed: int, noise_scale: float = 1.0):
+        """n joint posterior draws of the state path per trajectory: [n_save, D, n, N]."""
+        self._chk(self.lib.odef_sample(self._h, int(n), int(seed) & 0xFFFFFFFFFFFFFFFF, float(noise_scale)))
+        nb = self.field_bytes(F_SAMPLES)
+        a = np.empty(nb // 8)
+        self._chk(self.lib.odef_get(self._h, F_SAMPLES, a.ctypes.data_as(_vp), nb))
+        return a.reshape(self.n_save, self.D, int(n), self.N)
 
     def synchronize(self):
         self._chk(self.lib.odef_synchronize(self._h))
@@ -472,6 +481,17 @@ class EnsembleSolution:
         sm = self.smoothed if smoothed is None else smoothed
         m, c = self.ctx.dense_output(tq, sm)
         return m.transpose(2, 0, 1), unpack_tril(c.transpose(2, 0, 1), self.D)
+
+    def sample_states(self, n: int = 1, seed: int = 0x5A3B1E, noise_scale: float = 1.0) -> np.ndarray:
+        """`sample_states(sol, n)` (src/solution_sampling.jl:15-18, 24-62): [N, n_save, D, n] joint draws of the
+        state path from the smoothing posterior.  The reference asserts a smoothing solve (:16)."""
+        if not self.smoothed:
+            raise AssertionError("sampling not implemented for non-smoothed posteriors")
+        return self.ctx.sample_states(n, seed, noise_scale).transpose(3, 0, 1, 2)
+
+    def sample(self, n: int = 1, seed: int = 0x5A3B1E) -> np.ndarray:
+        """`sample(sol, n)` (src/solution_sampling.jl:19-23): [N, n_save, d, n]."""
+        return self.sample_states(n, seed)[:, :, : self.d, :]
 
     @property
     def diffusions(self) -> np.ndarray:

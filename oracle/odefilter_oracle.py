@@ -855,6 +855,78 @@ def dense_output(sol: Solution, consts, tval: float, smoothed: bool = True) -> S
 
 
 # --------------------------------------------------------------------------------------
+# Posterior sampling (solution_sampling.jl:24-62)
+# --------------------------------------------------------------------------------------
+
+
+def sample_normal(seed: int, traj: int, sample: int, slot: int, k: int, n_samples: int, n_save: int, D: int) -> float:
+    """The build's reproducible N(0,1) stream (the reference draws from Julia's global RNG, which cannot be
+    reproduced; only the distribution is part of the contract).  Counter c = ((traj*n_samples + sample)*n_save
+    + slot)*D + k;  U1, U2 = (splitmix64(seed + 2c [+1]) >> 11) * 2^-53;  Box-Muller on (1 - U1, U2)."""
+    c = (((traj * n_samples + sample) * n_save + slot) * D + k) & _M64
+    u1 = (splitmix64((seed + 2 * c) & _M64) >> 11) * 2.0**-53
+    u2 = (splitmix64((seed + 2 * c + 1) & _M64) >> 11) * 2.0**-53
+    return float(np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(6.283185307179586 * u2))
+
+
+def lower_factor(C: np.ndarray) -> np.ndarray:
+    """Lower-triangular L with L L' = C for PSD C, right-looking; a non-positive pivot zeroes its column
+    (the rule of the device kernels, ek_math.h chol_packed).  Same distribution as any other square root."""
+    A = np.array(C, float)
+    n = A.shape[0]
+    L = np.zeros_like(A)
+    for k in range(n):
+        piv = A[k, k]
+        if piv > 0.0:
+            L[k, k] = np.sqrt(piv)
+            L[k + 1:, k] = A[k + 1:, k] / L[k, k]
+            A[k + 1:, k + 1:] -= np.outer(L[k + 1:, k], L[k + 1:, k])
+    return L
+
+
+def sample_states(sol: Solution, consts, n: int = 1, seed: int = 0x5A3B1E, traj: int = 0, sqrt: str = "reference",
+                  noise_scale: float = 1.0, normal=None) -> np.ndarray:
+    """solution_sampling.jl:24-62 on the saved grid: draw x_N ~ N(mu_N, S_N), then backwards
+    x_i ~ smooth(x_filt[i], delta(x_{i+1})) in preconditioned coordinates.  Returns [n_save, D, n].
+    sqrt = "reference": the square root the reference multiplies the noise with (R' of its QR, :10);
+    sqrt = "cholesky":  the lower-triangular factor of the same covariance (what the device uses)."""
+    A, Q_L, precond, d, q = consts
+    D = d * (q + 1)
+    ts, xs = sol.t, sol.x_filt
+    ns = len(xs)
+    normal = normal or (lambda j, slot, k: sample_normal(seed, traj, j, slot, k, n, ns, D))
+    path = np.zeros((ns, D, n))
+
+    def draw(g: SRGaussian, j: int, slot: int) -> np.ndarray:
+        xi = np.array([normal(j, slot, k) for k in range(D)])
+        S = g.L if sqrt == "reference" else lower_factor(g.L @ g.L.T)
+        return g.mu + noise_scale * (S @ xi)  # _rand, :6-12
+
+    for j in range(n):
+        path[ns - 1, :, j] = draw(xs[-1], j, ns - 1)
+    for i in range(ns - 2, -1, -1):  # Julia i = length(xs)-1 .. 1
+        dt = ts[i + 1] - ts[i]
+        diffusion = sol.diffusions[i]  # i_diffusion = sum(difftimes .<= ts[i]) (1-based) == step t[i] -> t[i+1]
+        Qh = apply_diffusion(Q_L, diffusion)
+        P = precond(dt)
+        PI = 1.0 / P
+        for j in range(n):
+            nxt = SRGaussian(P * path[i + 1, :, j], np.zeros((D, D)))
+            prev_p, _ = smooth(linmap(P, xs[i]), nxt, A, Qh)
+            if sqrt == "reference":
+                path[i, :, j] = PI * draw(prev_p, j, i)
+            else:  # un-precondition first: chol(PI C PI) = PI chol(C), same sample up to rounding
+                path[i, :, j] = draw(linmap(PI, prev_p), j, i)
+    return path
+
+
+def sample(sol: Solution, consts, n: int = 1, **kw) -> np.ndarray:
+    """solution_sampling.jl:19-23: the zeroth-derivative part [n_save, d, n]."""
+    d = consts[3]
+    return sample_states(sol, consts, n, **kw)[:, :d, :]
+
+
+# --------------------------------------------------------------------------------------
 # Ensemble inputs (SURVEY.md 8d): bit-identical in Python / C / HIP
 # --------------------------------------------------------------------------------------
 

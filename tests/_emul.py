@@ -21,7 +21,7 @@ def build():
     src = os.path.join(HERE, "emul", "emul.cpp")
     out = os.path.join(HERE, "emul", "libodef_emul.so")
     deps = [src] + [os.path.join(ROOT, "odefilters.jl_amd", "csrc", f) for f in
-                    ("ek_math.h", "ek_lane.h", "rhs.h", "dispatch.h", "odef_platform.h", "team.h", "smooth_team.h", "filter_team.h", "smooth_rows.h", "smooth_lane.h", "dense_lane.h", "filter_tiles.h", "wave_vec.h")]
+                    ("ek_math.h", "ek_lane.h", "rhs.h", "dispatch.h", "odef_platform.h", "team.h", "smooth_team.h", "filter_team.h", "smooth_rows.h", "smooth_lane.h", "dense_lane.h", "filter_tiles.h", "wave_vec.h", "sample_lane.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++20", "-shared", "-fPIC", "-Wno-unknown-pragmas", src, "-o", out])
     return out
@@ -86,7 +86,7 @@ def unpack_tril(c, D):
 
 def emul_solve(rhs_id, d, q, ek1, u0s, p, *, team=False, tgrid=None, adaptive=False, t0=0.0, t1=1.0, abstol=1e-6, reltol=1e-3,
                dt0=1e-2, max_save=4096, everystep=True, fixed_diffusion=False, want_loglik=True, smooth=False,
-               ctrl=None, dense_t=None):
+               ctrl=None, dense_t=None, sample=None):
     """u0s [N, d]; p [np] shared.  Returns dict of numpy arrays in the device layout transposed
     to trajectory-major: mean [N, n_save, D], cov [N, n_save, D, D] ..."""
     u0s = np.asarray(u0s, float)
@@ -142,6 +142,15 @@ def emul_solve(rhs_id, d, q, ek1, u0s, p, *, team=False, tgrid=None, adaptive=Fa
         assert rc == 0, rc
         out["smean"] = smean.transpose(2, 0, 1)
         out["scov"] = unpack_tril(scov.transpose(2, 0, 1), D)
+    if sample is not None:  # (n_samples, seed, noise_scale)
+        class EmulSample(C.Structure):
+            _fields_ = [("a", C.POINTER(EmulArgs)), ("n_samples", C.c_long), ("seed", C.c_ulonglong), ("noise_scale", C.c_double), ("samples", dp)]
+        ns_, seed_, scale_ = sample
+        smp = np.zeros((n_save, D, ns_, N))
+        e = EmulSample(C.pointer(a), ns_, seed_, scale_, _p(smp))
+        rc = lib().emul_sample(C.byref(e), d)
+        assert rc == 0, rc
+        out["samples"] = smp.transpose(3, 0, 1, 2)  # [N, n_save, D, n_samples]
     if dense_t is not None:
         class EmulDense(C.Structure):
             _fields_ = [("a", C.POINTER(EmulArgs)), ("smoothed", C.c_int), ("tq", dp), ("n_q", C.c_long), ("qmean", dp), ("qcov", dp)]

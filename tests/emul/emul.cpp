@@ -10,6 +10,7 @@
 #include "../../odefilters.jl_amd/csrc/dense_lane.h"
 #include "../../odefilters.jl_amd/csrc/filter_team.h"
 #include "../../odefilters.jl_amd/csrc/filter_tiles.h"
+#include "../../odefilters.jl_amd/csrc/sample_lane.h"
 #include <vector>
 #include <cstring>
 
@@ -178,6 +179,43 @@ extern "C" int emul_dense(const EmulDense* e, int d) {
   P.tsave = a->tsave; P.nsaved = a->nsaved; P.mean = a->mean; P.cov = a->cov; P.diff = a->diff;
   P.smean = a->smean; P.scov = a->scov; P.tq = e->tq; P.n_q = e->n_q; P.qmean = e->qmean; P.qcov = e->qcov;
   RunDense r{P};
+  if (d == 2) return dispatch_smooth_order<2>(a->q, r);
+  if (d == 3) return dispatch_smooth_order<3>(a->q, r);
+  return -2;
+}
+
+// posterior sampling (sample_lane.h)
+struct EmulSample {
+  const EmulArgs* a;
+  long n_samples;
+  unsigned long long seed;
+  double noise_scale;
+  double* samples;
+};
+struct RunSample {
+  const SampleParams& P;
+  template <int d, int q>
+  void operator()() {
+    if constexpr (d * (q + 1) <= 12) {
+      constexpr int D = d * (q + 1);
+      std::vector<double> x(D * (D + 1) / 2);
+      for (long j = 0; j < P.n_samples; ++j)
+        for (long i = 0; i < P.N; ++i) sample_lane<d, q>(P, i, j, LaneMem{x.data(), 1});
+    }
+  }
+};
+extern "C" int emul_sample(const EmulSample* e, int d) {
+  const EmulArgs* a = e->a;
+  SampleParams P;
+  std::memset(&P, 0, sizeof P);
+  std::memcpy(P.pc.At, a->At, sizeof(P.pc.At));
+  std::memcpy(P.pc.Qt, a->Qt, sizeof(P.pc.Qt));
+  std::memcpy(P.pc.QLt, a->QLt, sizeof(P.pc.QLt));
+  P.N = a->N; P.n_save = a->n_save; P.adaptive = a->adaptive;
+  P.hs = a->hs; P.ptab = a->ptab; P.tab_idx = a->tab_idx;
+  P.tsave = a->tsave; P.nsaved = a->nsaved; P.mean = a->mean; P.cov = a->cov; P.diff = a->diff;
+  P.n_samples = e->n_samples; P.seed = e->seed; P.noise_scale = e->noise_scale; P.samples = e->samples;
+  RunSample r{P};
   if (d == 2) return dispatch_smooth_order<2>(a->q, r);
   if (d == 3) return dispatch_smooth_order<3>(a->q, r);
   return -2;

@@ -150,3 +150,29 @@ def test_dense_output(adaptive, smoothed):
         np.testing.assert_allclose(r["qmean"][0][j], ref.mu, rtol=1e-5, atol=1e-6, err_msg=f"t={t}")
         c = ref.cov()
         assert np.abs(r["qcov"][0][j] - c).max() <= 1e-6 * np.abs(c).max() + 1e-300, f"t={t}"
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_posterior_sampling(adaptive):
+    """sample_states (src/solution_sampling.jl:24-62) of the device source against the oracle with the same N(0,1)
+    stream and the same (lower-triangular) square root; the zero-noise chain reproduces the smoothed means."""
+    vf = orc.vector_field("lorenz63")
+    alg = orc.EK1(order=3)
+    if adaptive:
+        sol = orc.solve(vf, alg, adaptive=True, dt=2.0**-9, tspan=(0.0, 0.5))
+        kw = dict(adaptive=True, t0=0.0, t1=0.5, dt0=2.0**-9, max_save=256)
+    else:
+        sol = orc.solve(vf, alg, dt=2.0**-6, tspan=(0.0, 0.5))
+        kw = dict(tgrid=np.array(sol.t))
+    consts = orc.make_consts(3, 3)
+    seed, n = 1234, 3
+    r = E.emul_solve(vf.rhs_id, 3, 3, True, vf.u0[None, :], vf.p, smooth=True, sample=(n, seed, 1.0), **kw)
+    ns, cap = len(sol.t), r["samples"].shape[1]
+    S = r["samples"][0][:ns]
+    ref = orc.sample_states(sol, consts, n, sqrt="cholesky",
+                            normal=lambda j, slot, k: orc.sample_normal(seed, 0, j, slot, k, n, cap, 12))
+    scale = np.abs(ref).max(axis=(0, 2))[None, :, None]
+    err = (np.abs(S - ref) / scale).max(axis=(0, 2))
+    assert err[:3].max() < 1e-8 and err.max() < 1e-4, err  # u block / ill-conditioned derivative blocks
+    r0 = E.emul_solve(vf.rhs_id, 3, 3, True, vf.u0[None, :], vf.p, smooth=True, sample=(1, seed, 0.0), **kw)
+    np.testing.assert_allclose(r0["samples"][0][1:ns, :3, 0], sol.means(smoothed=True)[1:, :3], rtol=1e-7)

@@ -337,6 +337,61 @@ def test_dense_output_requires_smoothing_and_small_state(pkg):
     ctx.close()
 
 
+# ---- posterior sampling -----------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_posterior_sampling(pkg, adaptive):
+    """sample / sample_states (src/solution_sampling.jl) against the oracle with the same noise stream and square root,
+    plus the reference's own acceptance test (test/solution.jl:57-72: < 5 % outside 3 sigma)."""
+    vf = orc.vector_field("lorenz63")
+    N, t1, n, seed = 70, 0.5, 10, 99
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, (0.0, t1), vf.p), perturb_scale=1e-2)
+    if adaptive:
+        sol = pkg.solve(ens, pkg.EK1(order=3), pkg.EnsembleHIP(), trajectories=N, dt=2.0**-9, adaptive=True, max_steps=256)
+    else:
+        sol = pkg.solve(ens, pkg.EK1(order=3), pkg.EnsembleHIP(), trajectories=N, dt=2.0**-6, adaptive=False)
+    st = sol.sample_states(n, seed)
+    smp = sol.sample(n, seed)
+    cap = st.shape[1]
+    assert st.shape == (N, cap, 12, n) and smp.shape == (N, cap, 3, n)
+    np.testing.assert_array_equal(smp, st[:, :, :3, :])
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    consts = orc.make_consts(3, 3)
+    for i in (0, 69):
+        if adaptive:
+            ref = orc.solve(vf, orc.EK1(order=3), u0=u0s[i], tspan=(0.0, t1), dt=2.0**-9, adaptive=True)
+        else:
+            ref = orc.solve(vf, orc.EK1(order=3), u0=u0s[i], tspan=(0.0, t1), dt=2.0**-6)
+        ns = len(ref.t)
+        want = orc.sample_states(ref, consts, n, sqrt="cholesky",
+                                 normal=lambda j, slot, k: orc.sample_normal(seed, i, j, slot, k, n, cap, 12))
+        scale = np.abs(want).max(axis=(0, 2))[None, :, None]
+        err = (np.abs(st[i, :ns] - want) / scale).max(axis=(0, 2))
+        assert err[:3].max() < (1e-6 if adaptive else 1e-8) and err.max() < 1e-3, err
+        # the reference's acceptance test on the device samples
+        x = ref.means(smoothed=True)
+        stds = np.sqrt(np.array([np.diag(c) for c in ref.covs(smoothed=True)]))
+        out = np.abs(x[1:, :, None] - st[i, 1:ns]) > 3 * stds[1:, :, None] + 1e-12 * np.abs(x[1:, :, None])
+        assert out.sum() < 0.05 * out.size
+    # zero noise: the chain of conditional means is the smoothed mean
+    z = sol.sample_states(1, seed, noise_scale=0.0)[..., 0]
+    sm = sol.x_smooth_mean()
+    k = 5
+    np.testing.assert_allclose(z[:, 1:k, :3], sm[:, 1:k, :3], rtol=1e-7)
+    # reproducible, and a different seed gives different draws
+    np.testing.assert_array_equal(sol.sample_states(n, seed), st)
+    assert not np.array_equal(sol.sample_states(n, seed + 1), st)
+
+
+def test_sampling_needs_smoothing_solution(pkg):
+    vf = orc.vector_field("lorenz63")
+    prob = pkg.ODEProblem("lorenz63", vf.u0, (0.0, 0.1), vf.p)
+    sol = pkg.solve(prob, pkg.EK1(order=3, smooth=False), dt=2.0**-6, adaptive=False)
+    with pytest.raises(AssertionError, match="non-smoothed"):
+        sol.sample(2)
+
+
 # ---- edge cases ------------------------------------------------------------------------------------------
 
 

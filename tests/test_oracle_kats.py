@@ -213,3 +213,61 @@ def test_splitmix_reference_values():
     """splitmix64 known answers (Vigna's reference implementation, seed 0 -> first outputs)."""
     assert orc.splitmix64(0) == 0xE220A8397B1DCDAF
     assert orc.splitmix64(0x9E3779B97F4A7C15) == 0x6E789E6AA1B965F4
+
+
+# ---- posterior sampling (src/solution_sampling.jl, test/solution.jl:56-95) -----------------------------------
+
+
+def _sampling_solution():
+    vf = orc.vector_field("lotka_volterra")
+    sol = orc.solve(vf, orc.EK1(order=3), dt=2.0**-5, tspan=(0.0, 1.0))
+    return vf, sol, orc.make_consts(2, 3)
+
+
+def test_sampling_shapes_and_outliers():
+    """test/solution.jl:57-72, 82-95: shapes; fewer than 5 % of the draws lie outside 3 posterior standard deviations."""
+    vf, sol, consts = _sampling_solution()
+    n = 10
+    states = orc.sample_states(sol, consts, n)
+    assert states.shape == (len(sol.t), 8, n)
+    samples = orc.sample(sol, consts, n)
+    assert samples.shape == (len(sol.t), 2, n)
+    np.testing.assert_array_equal(samples, states[:, :2, :])
+    x = sol.means(smoothed=True)
+    stds = np.sqrt(np.array([np.diag(c) for c in sol.covs(smoothed=True)]))
+    out = np.abs(x[:, :, None] - states) > 3 * stds[:, :, None] + 1e-300
+    assert out[1:].sum() < 0.05 * states[1:].size  # index 0 is the exact initial value (zero variance)
+
+
+def test_sampling_zero_noise_is_the_smoothed_mean():
+    """With the noise switched off the backward recursion of conditional means reproduces the RTS means."""
+    vf, sol, consts = _sampling_solution()
+    z = orc.sample_states(sol, consts, 1, noise_scale=0.0)[:, :, 0]
+    sm = sol.means(smoothed=True)
+    np.testing.assert_allclose(z[1:, :2], sm[1:, :2], rtol=1e-9)
+
+
+def test_sampling_square_roots_share_the_covariance():
+    """The lower-triangular factor the device uses and the reference's QR square root are square roots of the same
+    conditional covariance (same distribution), and the device rule handles rank-deficient covariances."""
+    vf, sol, consts = _sampling_solution()
+    A, Q_L, precond, d, q = consts
+    i = len(sol.t) - 2
+    h = sol.t[i + 1] - sol.t[i]
+    P = precond(h)
+    nxt = orc.SRGaussian(P * sol.x_filt[i + 1].mu, np.zeros((8, 8)))
+    g, _ = orc.smooth(orc.linmap(P, sol.x_filt[i]), nxt, A, orc.apply_diffusion(Q_L, sol.diffusions[i]))
+    C = g.L @ g.L.T
+    L = orc.lower_factor(C)
+    assert np.allclose(L, np.tril(L))
+    assert np.abs(L @ L.T - C).max() <= 1e-10 * np.abs(C).max()
+    # exactly singular input: rank 1
+    v = np.array([1.0, 2.0, 0.0, -1.0])
+    L1 = orc.lower_factor(np.outer(v, v))
+    np.testing.assert_allclose(L1 @ L1.T, np.outer(v, v), atol=1e-14)
+
+
+def test_sample_normal_stream_moments():
+    xs = np.array([orc.sample_normal(7, 0, 0, s, k, 1, 4096, 12) for s in range(4096) for k in range(2)])
+    assert abs(xs.mean()) < 0.05 and abs(xs.std() - 1.0) < 0.05
+    assert orc.sample_normal(7, 0, 0, 5, 1, 1, 4096, 12) == orc.sample_normal(7, 0, 0, 5, 1, 1, 4096, 12)
