@@ -216,13 +216,20 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
   double ms[D];
   for (int w = 0; w < 2; ++w) {  // first and last record are copied (src/smoothing.jl:11)
     const long s = w == 0 ? 0 : n - 1;
+    {
+      double tmp[TRI];  // all loads in flight before the first store
+      const double* src = P.cov + ((size_t)s * TRI) * N + i;
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-      ms[k] = P.mean[((size_t)s * D + k) * N + i];
-      P.smean[((size_t)s * D + k) * N + i] = ms[k];
+      for (int k = 0; k < TRI; ++k) tmp[k] = src[(size_t)k * N];
+#pragma unroll
+      for (int k = 0; k < D; ++k) ms[k] = P.mean[((size_t)s * D + k) * N + i];
+      ODEF_SCHED_FENCE();
+      double* dst = P.scov + ((size_t)s * TRI) * N + i;
+#pragma unroll
+      for (int k = 0; k < TRI; ++k) dst[(size_t)k * N] = tmp[k];
+#pragma unroll
+      for (int k = 0; k < D; ++k) P.smean[((size_t)s * D + k) * N + i] = ms[k];
     }
-#pragma unroll
-    for (int k = 0; k < TRI; ++k) P.scov[((size_t)s * TRI + k) * N + i] = P.cov[((size_t)s * TRI + k) * N + i];
   }
   bool nan_seen = false;
   for (long s = n - 2; s >= 1; --s) {
@@ -254,18 +261,42 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
     }
     const double sigma2 = P.diff[(size_t)(s + 1) * N + i];
     // x_i and x_{i+1}^s in preconditioned coordinates (src/smoothing.jl:23-24)
+    // Phase 1: every load of the step in flight (raw values, running pointers, no arithmetic in between:
+    // a spill reload between two loads would make the compiler wait for the first one -- scratch and global
+    // loads share vmcnt -- and serialise 160 memory latencies per step).  Phase 2: scale.
     double mt[D], B[TRI], Cs[TRI];
+    {
+      const double* pc_ = P.cov + ((size_t)s * TRI) * N + i;
+      const double* ps_ = P.scov + ((size_t)(s + 1) * TRI) * N + i;
+      const double* pm_ = P.mean + ((size_t)s * D) * N + i;
 #pragma unroll
-    for (int k = 0; k < D; ++k) mt[k] = pj[k / d] * P.mean[((size_t)s * D + k) * N + i];
+      for (int k = 0; k < TRI; ++k) {
+        B[k] = *pc_;
+        pc_ += N;
+      }
+#pragma unroll
+      for (int k = 0; k < TRI; ++k) {
+        Cs[k] = *ps_;
+        ps_ += N;
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        mt[k] = *pm_;
+        pm_ += N;
+      }
+    }
+    ODEF_SCHED_FENCE();
+#pragma unroll
+    for (int k = 0; k < D; ++k) mt[k] *= pj[k / d];
 #pragma unroll
     for (int a = 0; a < D; ++a)
 #pragma unroll
       for (int b = 0; b <= a; ++b) {
         const double pp = pj[a / d] * pj[b / d];
-        const double x = P.cov[((size_t)s * TRI + tri(a, b)) * N + i] * pp;
+        const double x = B[tri(a, b)] * pp;
         xl.set(tri(a, b), x);
         B[tri(a, b)] = x;
-        Cs[tri(a, b)] = P.scov[((size_t)(s + 1) * TRI + tri(a, b)) * N + i] * pp;
+        Cs[tri(a, b)] *= pp;
       }
     double msn[D], msnew[D];
 #pragma unroll

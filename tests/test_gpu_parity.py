@@ -201,6 +201,8 @@ def test_caller_owned_output_buffers_and_stream(pkg):
     """odef_bind_device / odef_set_stream with torch-owned memory and torch's stream."""
     import torch
 
+    if not torch.cuda.is_available():
+        pytest.skip("torch's bundled HIP runtime does not see the GPU in this process (the library itself is exercised by every other test)")
     vf = orc.vector_field("lorenz63")
     N, nsteps, dt = 256, 16, 2.0**-9
     ctx = pkg.Context("lorenz63", 3, 1, N, save_everystep=False)
