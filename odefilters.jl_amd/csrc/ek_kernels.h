@@ -51,13 +51,17 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_num_vgpr(128))) void r
 // Smoother, one lane per trajectory (D <= 12): the read-only filter covariance of the step sits in
 // lane-private LDS (78 doubles x 64 lanes = 39 KB per wave at D = 12), everything else in registers.
 constexpr int kSmoothLaneMaxD = 12;
-template <int d, int q>
+// Two kernels (fixed grid / adaptive records) so that each gets its own register allocation.
+template <int d, int q, bool ADAPT>
 __global__ __launch_bounds__(kWave) void rts_smooth_lane_kernel(const SmoothParams P) {
   constexpr int D = d * (q + 1), TRI = D * (D + 1) / 2;
   __shared__ double lds[TRI * kWave];
   const long i0 = (long)blockIdx.x * kWave;
   const LaneMem xl{lds + threadIdx.x, kWave};
-  if (i0 + threadIdx.x < P.N) smooth_lane_v2<d, q>(P, i0, threadIdx.x, xl);
+  const bool valid = i0 + threadIdx.x < P.N;
+  long n_hi = P.n_save;
+  if constexpr (ADAPT) n_hi = wave_uniform_max(valid ? (long)P.nsaved[i0 + threadIdx.x] : 0, valid);
+  if (valid) smooth_lane_v2<d, q, ADAPT>(P, i0, threadIdx.x, xl, n_hi);
 }
 
 // Dense output: blockIdx.y = query time, one lane per trajectory (D <= 12).
@@ -91,7 +95,9 @@ __global__ __launch_bounds__(kWave) void sample_kernel(const SampleParams P) {
   __shared__ double lds[TRI * kWave];
   const long i = (long)blockIdx.x * kWave + threadIdx.x;
   const LaneMem xl{lds + threadIdx.x, kWave};
-  if (i < P.N) sample_lane<d, q>(P, i, (long)blockIdx.y, xl);
+  const bool valid = i < P.N;
+  const long n_hi = P.adaptive ? wave_uniform_max(valid ? (long)P.nsaved[i] : 0, valid) : P.n_save;
+  if (valid) sample_lane<d, q>(P, i, (long)blockIdx.y, xl, n_hi);
 }
 struct LaunchSample {
   const SampleParams& P;
@@ -179,7 +185,10 @@ struct LaunchSmooth {
   void operator()() {
     if constexpr (d * (q + 1) <= kSmoothLaneMaxD) {
       const unsigned grid = (unsigned)((P.N + kWave - 1) / kWave);
-      hipLaunchKernelGGL((rts_smooth_lane_kernel<d, q>), dim3(grid), dim3(kWave), 0, s, P);
+      if (P.adaptive)
+        hipLaunchKernelGGL((rts_smooth_lane_kernel<d, q, true>), dim3(grid), dim3(kWave), 0, s, P);
+      else
+        hipLaunchKernelGGL((rts_smooth_lane_kernel<d, q, false>), dim3(grid), dim3(kWave), 0, s, P);
     } else {
       constexpr int TPB = kWave / SmoothTeam<d * (q + 1)>::lanes;
       const unsigned grid = (unsigned)((P.N + TPB - 1) / TPB);

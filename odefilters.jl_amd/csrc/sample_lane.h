@@ -64,7 +64,7 @@ __device__ inline void draw_packed(const double (&m)[D], double (&C)[D * (D + 1)
 }
 
 template <int d, int q>
-__device__ inline void sample_lane(const SampleParams& P, long i, long j, const LaneMem& xl) {
+__device__ inline void sample_lane(const SampleParams& P, long i, long j, const LaneMem& xl, long n_hi) {
   constexpr int NB = q + 1, D = d * NB, TRI = D * (D + 1) / 2;
   const size_t N = (size_t)P.N, NS = (size_t)P.n_samples;
   const long n = P.adaptive ? (long)P.nsaved[i] : P.n_save;
@@ -82,7 +82,8 @@ __device__ inline void sample_lane(const SampleParams& P, long i, long j, const 
 #pragma unroll
     for (int k = 0; k < D; ++k) out(n - 1, k) = xs[k];
   }
-  for (long s = n - 2; s >= 0; --s) {
+  for (long s = n_hi - 2; s >= 0; --s) {  // wave-uniform slot, see wave_uniform_max (smooth_lane.h)
+    if (s > n - 2) continue;
     double h, pj[NB], pij[NB];
     if (P.adaptive) {
       h = P.tsave[(size_t)(s + 1) * N + i] - P.tsave[(size_t)s * N + i];

@@ -204,11 +204,33 @@ __device__ inline void rts_step_core(const PriorConsts& pc, const double (&pij)[
   });
 }
 
-template <int d, int q>
-__device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned lane, const LaneMem& xl) {
+// Largest value of v over the lanes of the wavefront that are inside the batch, as a wave-uniform scalar.
+// Adaptive solves store a different number of records per trajectory; walking the SAME save slot in all lanes of
+// a wavefront (lanes join when the slot reaches their own last record) keeps every record access a contiguous
+// 512-byte row.  Walking each lane from its own end instead touched ~10 different slots per load instruction and
+// ran the adaptive smoother 8x slower per step.
+__device__ inline long wave_uniform_max(long v, bool valid) {
+#ifdef ODEF_HOST_EMUL
+  (void)valid;
+  return v;
+#else
+  int x = valid ? (int)v : 0;
+  for (int m = 32; m >= 1; m >>= 1) {
+    const int y = __shfl_xor(x, m, 64);
+    x = x > y ? x : y;
+  }
+  return (long)__builtin_amdgcn_readfirstlane(x);
+#endif
+}
+
+// `n_hi`: wave-uniform upper bound of the record count of the lanes of this wavefront (fixed grid: n_save).
+// ADAPT: per-trajectory record counts and step sizes (adaptive solve); otherwise everything about the grid is
+// wave-uniform and comes from the host tables.
+template <int d, int q, bool ADAPT>
+__device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned lane, const LaneMem& xl, long n_hi) {
   constexpr int NB = q + 1, D = d * NB, TRI = D * (D + 1) / 2;
   const long i = i0 + lane;
-  const long n = P.adaptive ? (long)P.nsaved[i] : P.n_save;
+  const long n = ADAPT ? (long)P.nsaved[i] : P.n_save;
   const size_t N = (size_t)P.N;
   const PriorConsts& pc = P.pc;
   // The smoothed covariance of time i+1 is NOT carried in registers: it is re-read from the record
@@ -232,9 +254,23 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
     }
   }
   bool nan_seen = false;
-  for (long s = n - 2; s >= 1; --s) {
+  // The slot index walks the same value in every lane but is deliberately kept in a VGPR: with a scalar slot
+  // the compiler moves the record address arithmetic to the SALU (s_mul chains, SGPR spills, hazard nops in
+  // front of the loads) and the fixed-grid smoother measured 44 ms instead of 39 ms.
+  long s_start = n_hi - 2;
+#ifndef ODEF_HOST_EMUL
+  {
+    int lo = (int)s_start;
+    asm volatile("" : "+v"(lo));
+    s_start = lo;
+  }
+#endif
+  for (long s = s_start; s >= 1; --s) {
+    if constexpr (ADAPT) {
+      if (s > n - 2) continue;  // this trajectory has fewer records: it joins at its own last one
+    }
     double h, pj[NB], pij[NB];
-    if (P.adaptive) {
+    if constexpr (ADAPT) {
       h = P.tsave[(size_t)(s + 1) * N + i] - P.tsave[(size_t)s * N + i];
       double val = (h != 0.0) ? precond_val<q>(h) : 1.0;
 #pragma unroll

@@ -70,7 +70,12 @@ struct RunSmooth {
     if constexpr (d * (q + 1) <= 12) {  // lane-per-trajectory smoother, lane-private memory = a plain array here
       constexpr int D = d * (q + 1);
       std::vector<double> x(D * (D + 1) / 2);
-      for (long i = 0; i < P.N; ++i) smooth_lane_v2<d, q>(P, i, 0, LaneMem{x.data(), 1});
+      for (long i = 0; i < P.N; ++i) {
+        if (P.adaptive)
+          smooth_lane_v2<d, q, true>(P, i, 0, LaneMem{x.data(), 1}, (long)P.nsaved[i]);
+        else
+          smooth_lane_v2<d, q, false>(P, i, 0, LaneMem{x.data(), 1}, P.n_save);
+      }
     } else if constexpr (d * (q + 1) <= 32) {  // row-per-lane teams: all lanes of a team emulated phase by phase
       constexpr int D = d * (q + 1), TEAM = (D <= 16) ? 16 : 32;
       std::vector<double> ws(RowsWs<d, q + 1>::size);
@@ -200,7 +205,7 @@ struct RunSample {
       constexpr int D = d * (q + 1);
       std::vector<double> x(D * (D + 1) / 2);
       for (long j = 0; j < P.n_samples; ++j)
-        for (long i = 0; i < P.N; ++i) sample_lane<d, q>(P, i, j, LaneMem{x.data(), 1});
+        for (long i = 0; i < P.N; ++i) sample_lane<d, q>(P, i, j, LaneMem{x.data(), 1}, P.adaptive ? (long)P.nsaved[i] : P.n_save);
     }
   }
 };
