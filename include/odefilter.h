@@ -151,7 +151,12 @@ int odef_set_problem_perturbed(odef_ctx* ctx, const double* base_u0, const doubl
 
 /* Fixed-step filter over the host time grid tgrid[0..n_t-1] (n_t-1 steps for every trajectory). */
 int odef_solve_fixed(odef_ctx* ctx, const double* tgrid, int64_t n_t);
-/* Adaptive filter from t0 to t1; at most max_steps accepted steps are stored per trajectory. */
+/* Adaptive filter from t0 to t1.  ONE RECORD PER ATTEMPTED STEP (at most max_steps per trajectory, NSAVED = attempts
+ * + 1): an accepted step stores the new state at the new time, a rejected attempt stores the unchanged state again at
+ * the unchanged time.  All lanes of a wavefront then write record k in the same instructions (full 512-byte rows);
+ * odef_smooth / odef_dense_output / odef_sample treat the repeated record as the reference treats a duplicated save
+ * time (src/smoothing.jl:13-16).  A binding that wants the reference's sol.t / sol.u (accepted steps only,
+ * src/integrator_utils.jl:33-48) drops records whose T equals the previous T (host.py EnsembleSolution._order). */
 int odef_solve_adaptive(odef_ctx* ctx, double t1, double abstol, double reltol, double dt0,
                         const odef_controller* ctrl, int64_t max_steps);
 /* Rauch-Tung-Striebel pass over the stored filter states. */

@@ -196,7 +196,14 @@ __device__ inline void load_state_scatter(const FilterParams& P, long slot, long
 // Adaptive filter: perform_step! + error estimate (src/perform_step.jl:78-92) + the PI
 // controller of OrdinaryDiffEq (third-party; exponents src/alg_utils.jl:23-24).
 // Only ONE copy of the state is kept in registers: the candidate x_filt overwrites it, and the rare
-// rejected step re-reads the previous accepted state from its save slot (every accepted state is saved).
+// rejected step re-reads the previous record.
+// Record layout: ONE RECORD PER ATTEMPTED STEP.  All lanes of a wavefront attempt their k-th step in the same
+// loop iteration, so record k of every lane is written by the same store instructions: full 512-byte rows.  A
+// rejected attempt writes the unchanged state again with the unchanged time -- a zero-length step, which the
+// smoother, the dense output and the sampler skip exactly as the reference skips duplicated save times
+// (src/smoothing.jl:13-16); the host mirror drops those records when it builds sol.t / sol.u.  Storing accepted
+// steps only (slot = accepted count, different per lane after the first rejection) splits every store
+// instruction over 3-4 rows and ran 3x slower (1.1 TB/s of scattered 8-byte writes).
 template <class RHS, int q, bool IS_EK1>
 __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsigned lane) {
   const long i = i0 + lane;
@@ -267,7 +274,7 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
     const bool accepted = EEst <= 1.0;  // OrdinaryDiffEq accepts on <=
     if (!(EEst < 1.0)) {
       // x_filt is not committed (src/perform_step.jl:89): cache.x stays P^-1 (P x) of the old state (:73)
-      load_state_scatter<D, TRI>(P, nsaved - 1, i, m, C);
+      load_state_scatter<D, TRI>(P, nsaved - 1, i, m, C);  // the previous record holds the current accepted state
 #pragma unroll
       for (int k = 0; k < D; ++k) m[k] = tab[kTabPIJ + k / d] * (tab[kTabPJ + k / d] * m[k]);
     }
@@ -280,14 +287,15 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
       t = tn;
       gdiff = aux.sigma2_global;
       ++naccept;
-      store_state_scatter<D, TRI>(P, nsaved, i, m, C, gdiff, t);
-      ++nsaved;
       h = h / qq;
-      if (!all_finite<D>(m)) { ret = 3; break; }
     } else {
       ++nreject;
       h = h / fmin(1.0 / ct.qmin, q11 / ct.gamma);
     }
+    // accepted: the new state at the new time; rejected: the old state again at the old time
+    store_state_scatter<D, TRI>(P, nsaved, i, m, C, gdiff, t);
+    ++nsaved;
+    if (accepted && !all_finite<D>(m)) { ret = 3; break; }
   }
   P.loglik[i] = loglik;
   P.naccept[i] = naccept;

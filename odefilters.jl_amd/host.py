@@ -437,26 +437,56 @@ class EnsembleSolution:
             self._cache[f] = self.ctx.get(f)
         return self._cache[f]
 
+    # Adaptive solves keep one device record per ATTEMPTED step; a rejected attempt repeats the previous record at
+    # the unchanged time (include/odefilter.h, odef_solve_adaptive).  The reference saves accepted steps only
+    # (src/integrator_utils.jl:33-48), so the accessors below drop the repeats.
+    def _order(self):
+        """(order [N, n_save], count [N]): per trajectory the record indices with the kept ones first."""
+        if "_order" not in self._cache:
+            tt = self._get(F_T).T
+            ns = self._get(F_NSAVED)
+            idx = np.arange(tt.shape[1])[None, :]
+            keep = idx < ns[:, None]
+            keep[:, 1:] &= tt[:, 1:] != tt[:, :-1]
+            self._cache["_order"] = (np.argsort(~keep, axis=1, kind="stable"), keep.sum(axis=1).astype(np.int32))
+        return self._cache["_order"]
+
+    def raw_index(self, i: int) -> np.ndarray:
+        """Device record index of every kept record of trajectory i (identity for fixed grids)."""
+        if not self.adaptive:
+            return np.arange(self.ctx.n_save)
+        order, count = self._order()
+        return order[i, : count[i]]
+
+    def _compact(self, a: np.ndarray) -> np.ndarray:
+        """a: [N, n_save, ...] -> same shape, kept records first, the rest zero."""
+        if not self.adaptive:
+            return a
+        order, count = self._order()
+        out = np.take_along_axis(a, order.reshape(order.shape + (1,) * (a.ndim - 2)), axis=1)
+        out[np.arange(a.shape[1])[None, :] >= count[:, None]] = 0
+        return out
+
     @property
     def t(self) -> np.ndarray:
         t = self._get(F_T)
-        return t.T if t.ndim == 2 else t
+        return self._compact(t.T) if t.ndim == 2 else t
 
     @property
     def nsaved(self) -> np.ndarray:
-        return self._get(F_NSAVED)
+        return self._order()[1] if self.adaptive else self._get(F_NSAVED)
 
     def x_filt_mean(self) -> np.ndarray:
-        return self._get(F_MEAN).transpose(2, 0, 1)
+        return self._compact(self._get(F_MEAN).transpose(2, 0, 1))
 
     def x_filt_cov(self) -> np.ndarray:
-        return unpack_tril(self._get(F_COV_TRIL).transpose(2, 0, 1), self.D)
+        return unpack_tril(self._compact(self._get(F_COV_TRIL).transpose(2, 0, 1)), self.D)
 
     def x_smooth_mean(self) -> np.ndarray:
-        return self._get(F_SMOOTH_MEAN).transpose(2, 0, 1)
+        return self._compact(self._get(F_SMOOTH_MEAN).transpose(2, 0, 1))
 
     def x_smooth_cov(self) -> np.ndarray:
-        return unpack_tril(self._get(F_SMOOTH_COV_TRIL).transpose(2, 0, 1), self.D)
+        return unpack_tril(self._compact(self._get(F_SMOOTH_COV_TRIL).transpose(2, 0, 1)), self.D)
 
     @property
     def smoothed(self) -> bool:
@@ -487,7 +517,7 @@ class EnsembleSolution:
         state path from the smoothing posterior.  The reference asserts a smoothing solve (:16)."""
         if not self.smoothed:
             raise AssertionError("sampling not implemented for non-smoothed posteriors")
-        return self.ctx.sample_states(n, seed, noise_scale).transpose(3, 0, 1, 2)
+        return self._compact(self.ctx.sample_states(n, seed, noise_scale).transpose(3, 0, 1, 2))
 
     def sample(self, n: int = 1, seed: int = 0x5A3B1E) -> np.ndarray:
         """`sample(sol, n)` (src/solution_sampling.jl:19-23): [N, n_save, d, n]."""
@@ -496,7 +526,7 @@ class EnsembleSolution:
     @property
     def diffusions(self) -> np.ndarray:
         """[N, n_save-1]: entry k = diffusion of step t[k] -> t[k+1] (src/integrator_utils.jl:44)."""
-        return self._get(F_DIFFUSION).T[:, 1:]
+        return self._compact(self._get(F_DIFFUSION).T)[:, 1:]
 
     @property
     def log_likelihood(self) -> np.ndarray:

@@ -151,6 +151,24 @@ def emul_solve(rhs_id, d, q, ek1, u0s, p, *, team=False, tgrid=None, adaptive=Fa
         rc = lib().emul_sample(C.byref(e), d)
         assert rc == 0, rc
         out["samples"] = smp.transpose(3, 0, 1, 2)  # [N, n_save, D, n_samples]
+    if adaptive:
+        # one record per ATTEMPTED step on the device side; drop the repeats of rejected attempts (unchanged time),
+        # as host.py EnsembleSolution does, so that the arrays line up with the reference's accepted-only records
+        ns_raw = ints[4].copy()
+        out["nsaved_raw"] = ns_raw
+        tt = tsave.T
+        keep = np.arange(n_save)[None, :] < ns_raw[:, None]
+        keep[:, 1:] &= tt[:, 1:] != tt[:, :-1]
+        order = np.argsort(~keep, axis=1, kind="stable")
+        count = keep.sum(axis=1).astype(np.int32)
+        out["raw_index"] = [order[i, : count[i]] for i in range(N)]
+        out["nsaved"] = count
+        for key in ("mean", "cov", "diff", "tsave", "smean", "scov", "samples"):
+            if key in out:
+                arr = out[key]
+                c = np.take_along_axis(arr, order.reshape(order.shape + (1,) * (arr.ndim - 2)), axis=1)
+                c[np.arange(n_save)[None, :] >= count[:, None]] = 0
+                out[key] = c
     if dense_t is not None:
         class EmulDense(C.Structure):
             _fields_ = [("a", C.POINTER(EmulArgs)), ("smoothed", C.c_int), ("tq", dp), ("n_q", C.c_long), ("qmean", dp), ("qcov", dp)]

@@ -169,8 +169,11 @@ def test_posterior_sampling(adaptive):
     r = E.emul_solve(vf.rhs_id, 3, 3, True, vf.u0[None, :], vf.p, smooth=True, sample=(n, seed, 1.0), **kw)
     ns, cap = len(sol.t), r["samples"].shape[1]
     S = r["samples"][0][:ns]
+    raw = r["raw_index"][0] if adaptive else np.arange(ns)  # device slot of the k-th accepted record
+    # a rejected attempt repeats the record; the draw of a repeated state is made at its LAST repeat
+    raw = np.append(raw[1:] - 1, raw[-1])
     ref = orc.sample_states(sol, consts, n, sqrt="cholesky",
-                            normal=lambda j, slot, k: orc.sample_normal(seed, 0, j, slot, k, n, cap, 12))
+                            normal=lambda j, slot, k: orc.sample_normal(seed, 0, j, int(raw[slot]), k, n, cap, 12))
     scale = np.abs(ref).max(axis=(0, 2))[None, :, None]
     err = (np.abs(S - ref) / scale).max(axis=(0, 2))
     assert err[:3].max() < 1e-8 and err.max() < 1e-4, err  # u block / ill-conditioned derivative blocks
