@@ -80,14 +80,25 @@ function DiffEqBase.__solve(eprob::DiffEqBase.EnsembleProblem, alg::Union{EK0,EK
         ns = Int(ccall((:odef_n_save, LIB), Int64, (Ptr{Cvoid},), ctx))
         mean = fetch(ctx, alg.smooth ? F_SMOOTH_MEAN : F_MEAN, Float64, N, D, ns)
         cov  = fetch(ctx, alg.smooth ? F_SMOOTH_COV_TRIL : F_COV_TRIL, Float64, N, TRI, ns)
-        return (t = adaptive ? fetch(ctx, F_T, Float64, N, ns) : fetch(ctx, F_T, Float64, ns),
+        tsave = adaptive ? fetch(ctx, F_T, Float64, N, ns) : fetch(ctx, F_T, Float64, ns)
+        nsaved = fetch(ctx, F_NSAVED, Int32, N)
+        # Adaptive solves hold one record per ATTEMPTED step: a rejected attempt repeats the previous record at the
+        # unchanged time (include/odefilter.h, odef_solve_adaptive).  `keep[i, s]` marks the records the reference
+        # would have saved (accepted steps only, src/integrator_utils.jl:33-48): x[i, :, keep[i, :]].
+        keep = trues(N, ns)
+        if adaptive
+            for i in 1:N, s in 1:ns
+                keep[i, s] = s <= nsaved[i] && (s == 1 || tsave[i, s] != tsave[i, s - 1])
+            end
+        end
+        return (t = tsave, keep = keep,
                 u = view(mean, :, 1:d, :), x_mean = mean, x_cov_tril = cov,
                 x_filt_mean = fetch(ctx, F_MEAN, Float64, N, D, ns),
                 diffusions = fetch(ctx, F_DIFFUSION, Float64, N, ns)[:, 2:end],
                 log_likelihood = fetch(ctx, F_LOGLIK, Float64, N),
                 destats = (nf = fetch(ctx, F_NF, Int32, N), njacs = fetch(ctx, F_NJAC, Int32, N),
                            naccept = fetch(ctx, F_NACCEPT, Int32, N), nreject = fetch(ctx, F_NREJECT, Int32, N)),
-                nsaved = fetch(ctx, F_NSAVED, Int32, N),
+                nsaved = nsaved,
                 retcode = [RETCODES[r + 1] for r in fetch(ctx, F_RETCODE, Int32, N)])
     finally
         ccall((:odef_destroy, LIB), Cvoid, (Ptr{Cvoid},), ctx)
