@@ -17,7 +17,7 @@ namespace odef {
 
 constexpr int kWave = 64;
 
-template <class RHS, int q, bool EK1>
+template <class RHS, int q, bool EK1, bool EVERY>
 __global__ __launch_bounds__(kWave) void ek_filter_fixed_kernel(const FilterParams P) {
   const long i0 = (long)blockIdx.x * kWave;  // wave-uniform
   // All waves run the same instruction stream and would reach their per-step store burst
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(kWave) void ek_filter_fixed_kernel(const FilterPara
     const int n = (int)(blockIdx.x % 16u) * P.stagger;
     for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
   }
-  if (i0 + threadIdx.x < P.N) filter_fixed_lane<RHS, q, EK1>(P, i0, threadIdx.x);
+  if (i0 + threadIdx.x < P.N) filter_fixed_lane<RHS, q, EK1, EVERY>(P, i0, threadIdx.x);
 }
 template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kWave) void ek_filter_adaptive_kernel(const FilterParams P) {
@@ -175,7 +175,8 @@ struct LaunchFilter {
   void operator()() {
     const unsigned grid = (unsigned)((P.N + kWave - 1) / kWave);
     if (adaptive) hipLaunchKernelGGL((ek_filter_adaptive_kernel<RHS, q, EK1>), dim3(grid), dim3(kWave), 0, s, P);
-    else hipLaunchKernelGGL((ek_filter_fixed_kernel<RHS, q, EK1>), dim3(grid), dim3(kWave), 0, s, P);
+    else if (P.everystep) hipLaunchKernelGGL((ek_filter_fixed_kernel<RHS, q, EK1, true>), dim3(grid), dim3(kWave), 0, s, P);
+    else hipLaunchKernelGGL((ek_filter_fixed_kernel<RHS, q, EK1, false>), dim3(grid), dim3(kWave), 0, s, P);
   }
 };
 struct LaunchSmooth {

@@ -53,21 +53,19 @@ struct FilterParams {
 struct RowStore {
   double* p;
   size_t n;
-  bool on;
-  RowStore(double* base, size_t N, size_t /*rows*/, unsigned lane, bool enabled = true) : p(base + lane), n(N), on(enabled) {}
-  void put(double v) { if (on) { *p = v; p += n; } }
+  RowStore(double* base, size_t N, size_t /*rows*/, unsigned lane) : p(base + lane), n(N) {}
+  void put(double v) { *p = v; p += n; }
 };
 #else
 struct RowStore {
   __amdgpu_buffer_rsrc_t rs;
   unsigned voff, soff, step;
-  bool on;  // wave-uniform
-  __device__ RowStore(double* base, size_t N, size_t rows, unsigned lane, bool enabled = true)
+  __device__ RowStore(double* base, size_t N, size_t rows, unsigned lane)
       : rs(__builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(rows * N * sizeof(double)), 0x00020000)),
-        voff(lane * 8u), soff(0u), step((unsigned)(N * sizeof(double))), on(enabled) {}
+        voff(lane * 8u), soff(0u), step((unsigned)(N * sizeof(double))) {}
   __device__ void put(double v) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    if (on) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, 0);
     soff += step;
     asm volatile("" : "+s"(soff));  // keep the row offset a running scalar (one s_add per store) instead of
                                     // dozens of hoisted loop-invariant offsets that would spill the SGPR file
@@ -106,7 +104,9 @@ __device__ inline bool all_finite(const double (&m)[D]) {
   return ok;
 }
 
-template <class RHS, int q, bool IS_EK1>
+// EVERY: every step is saved (compile-time: with a run-time flag each of the 91 stores of a step sat behind
+// its own branch, which cost 10 % in instructions and scheduling).
+template <class RHS, int q, bool IS_EK1, bool EVERY>
 __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigned lane) {
   const long i = i0 + lane;
   using S = EKStep<RHS, q, IS_EK1>;
@@ -122,7 +122,7 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigne
   taylor_init<RHS, q>(u0, pl, m);
 #pragma unroll
   for (int k = 0; k < TRI; ++k) C[k] = 0.0;
-  if (P.everystep) store_state<D, TRI>(P, 0, i0, lane, m, C, 0.0);
+  if constexpr (EVERY) store_state<D, TRI>(P, 0, i0, lane, m, C, 0.0);
 
   double loglik = 0.0, gdiff = 0.0;
   int chol_fix = 0;
@@ -132,9 +132,14 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigne
     StepAux aux;
     aux.chol_fix = 0;
     const size_t Nn = (size_t)P.N;
-    RecordSink sink{RowStore(P.mean + ((size_t)(n + 1) * D * Nn + i0), Nn, D, lane, P.everystep != 0),
-                    RowStore(P.cov + ((size_t)(n + 1) * TRI * Nn + i0), Nn, TRI, lane, P.everystep != 0)};
-    S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux, sink);
+    if constexpr (EVERY) {
+      RecordSink sink{RowStore(P.mean + ((size_t)(n + 1) * D * Nn + i0), Nn, D, lane),
+                      RowStore(P.cov + ((size_t)(n + 1) * TRI * Nn + i0), Nn, TRI, lane)};
+      S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux, sink);
+    } else {
+      NoSink nosink;
+      S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux, nosink);
+    }
 #pragma unroll
     for (int k = 0; k < D; ++k) m[k] = m2[k];
 #pragma unroll
@@ -142,18 +147,18 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigne
     loglik += aux.loglik;
     gdiff = aux.sigma2_global;
     chol_fix += aux.chol_fix;
-    if (P.everystep) {
+    if constexpr (EVERY) {
       RowStore sd(P.diff + ((size_t)(n + 1) * Nn + i0), Nn, 1, lane);
       sd.put(gdiff);
     }
   }
-  if (!P.everystep) store_state<D, TRI>(P, 0, i0, lane, m, C, gdiff);
+  if constexpr (!EVERY) store_state<D, TRI>(P, 0, i0, lane, m, C, gdiff);
   P.loglik[i] = loglik;
   P.naccept[i] = (int)P.nsteps;
   P.nreject[i] = 0;
   P.nf[i] = (int)P.nsteps;
   P.njac[i] = IS_EK1 ? (int)P.nsteps : 0;
-  P.nsaved[i] = P.everystep ? (int)P.nsteps + 1 : 1;
+  P.nsaved[i] = EVERY ? (int)P.nsteps + 1 : 1;
   (void)chol_fix;
   P.retcode[i] = all_finite<D>(m) ? 0 /*Success*/ : 3 /*Unstable*/;
 }

@@ -59,7 +59,8 @@ struct RunFilter {
     for (long i = 0; i < P.N; ++i) {
       const long i0 = (i / 64) * 64;
       if (adaptive) filter_adaptive_lane<RHS, q, EK1>(P, i0, (unsigned)(i - i0));
-      else filter_fixed_lane<RHS, q, EK1>(P, i0, (unsigned)(i - i0));
+      else if (P.everystep) filter_fixed_lane<RHS, q, EK1, true>(P, i0, (unsigned)(i - i0));
+      else filter_fixed_lane<RHS, q, EK1, false>(P, i0, (unsigned)(i - i0));
     }
   }
 };
