@@ -24,6 +24,7 @@
  *                                                                                src/smoothing.jl:4-63
  *   odef_dense_output               sol(t), GaussianODEFilterPosterior            src/solution.jl:165-214
  *   odef_sample                     sample_states / sample                        src/solution_sampling.jl:15-62
+ *   odef_rhs_compile                the user's f / f.jac closure (compiled, not called) src/perform_step.jl:106,116-121
  *   odef_get / odef_get_device      sol.t, sol.x_filt, sol.x_smooth, sol.diffusions, sol.log_likelihood,
  *                                   sol.destats, sol.retcode                     src/solution.jl:8-24
  *   odef_predict / odef_update /
@@ -132,6 +133,25 @@ typedef struct {
 
 int odef_version(void);
 const char* odef_last_error(const odef_ctx* ctx); /* ctx may be NULL: last error of odef_create */
+
+/* Run-time compiled vector field.  The reference calls the user's Julia closure f (and f.jac or ForwardDiff) in the
+ * middle of every step (src/perform_step.jl:106,116-121); a device kernel cannot call back into the host, so the
+ * vector field is handed over as HIP C++ SOURCE: the definition of a struct `name` with the interface of the
+ * compiled-in registry (odefilters.jl_amd/csrc/rhs.h), placed inside namespace odef:
+ *
+ *     struct MyField {
+ *       static constexpr int d = 3, np = 3;
+ *       template <class T>   // T = double in the step, a truncated Taylor jet in the initialisation
+ *       __device__ static void f(const T (&u)[3], const double* p, T (&du)[3]) { ... }
+ *       __device__ static void jac(const double (&u)[3], const double* p, double (&J)[3][3]) { ... }  // EK1
+ *     };
+ *
+ * hiprtc compiles the library's own lane kernels around it for gfx950 (include_dir = directory holding the csrc
+ * headers; NULL: $ODEFILTER_HIP_INCLUDE or the build-time location).  Returns 0 and a new rhs id (>= 100) for
+ * odef_config.rhs_id; on a compile error returns -1 and odef_last_error(NULL) holds the compiler log.
+ * Filter: d(q+1) <= 15; smoother, dense output and sampling: d(q+1) <= 12. */
+int odef_rhs_compile(const char* name, const char* source, int32_t d, int32_t n_params, const char* include_dir,
+                     int32_t* rhs_id);
 
 int odef_create(odef_ctx** out, const odef_config* cfg);
 void odef_destroy(odef_ctx* ctx);

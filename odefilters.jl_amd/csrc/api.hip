@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/odefilter.h"
+#include "jit.h"
 #include "launch.h"
 
 using namespace odef;
@@ -62,6 +63,7 @@ struct odef_ctx {
   bool adaptive = false;
   bool solved = false;
   bool team_path = false;   // workgroup-per-trajectory kernels (large state dimension)
+  JitModule* jit = nullptr; // run-time compiled vector field (rhs_id >= 100); owned by the registry in jit.hip
   double* d_ws = nullptr;   // per-trajectory workspace of the team kernels
   size_t ws_cap = 0;
   Buf f[ODEF_F_COUNT_];
@@ -241,13 +243,30 @@ int odef_version(void) { return ODEF_VERSION; }
 
 const char* odef_last_error(const odef_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+int odef_rhs_compile(const char* name, const char* source, int32_t d, int32_t n_params, const char* include_dir, int32_t* rhs_id) {
+  if (!rhs_id) return fail(nullptr, "odef_rhs_compile: null rhs_id");
+  std::string err;
+  const int id = jit_register(name, source, d, n_params, include_dir, err);
+  if (id < 0) {
+    g_create_error = err;  // the whole compiler log, not truncated
+    return -1;
+  }
+  *rhs_id = id;
+  return 0;
+}
+
 int odef_create(odef_ctx** out, const odef_config* cfg) {
   if (!out || !cfg) return fail(nullptr, "odef_create: null argument");
   *out = nullptr;
   if (cfg->struct_size != (int32_t)sizeof(odef_config))
     return fail(nullptr, "odef_create: struct_size %d != %zu", cfg->struct_size, sizeof(odef_config));
-  if (cfg->rhs_id < 0 || cfg->rhs_id > ODEF_RHS_PLEIADES) return fail(nullptr, "odef_create: unknown rhs_id %d", cfg->rhs_id);
-  const RhsInfo ri = kRhs[cfg->rhs_id];
+  RhsInfo ri{0, 0};
+  if (cfg->rhs_id >= kJitFirstId) {
+    if (!jit_lookup(cfg->rhs_id, &ri.d, &ri.np)) return fail(nullptr, "odef_create: unknown run-time rhs_id %d", cfg->rhs_id);
+  } else {
+    if (cfg->rhs_id < 0 || cfg->rhs_id > ODEF_RHS_PLEIADES) return fail(nullptr, "odef_create: unknown rhs_id %d", cfg->rhs_id);
+    ri = kRhs[cfg->rhs_id];
+  }
   if (cfg->d != ri.d) return fail(nullptr, "odef_create: rhs %d has dimension %d, got d=%d", cfg->rhs_id, ri.d, cfg->d);
   if (cfg->n_params != ri.np) return fail(nullptr, "odef_create: rhs %d has %d parameters, got %d", cfg->rhs_id, ri.np, cfg->n_params);
   if (cfg->order < 1 || cfg->order > ODEF_MAX_ORDER) return fail(nullptr, "odef_create: order %d outside 1..%d", cfg->order, ODEF_MAX_ORDER);
@@ -255,6 +274,8 @@ int odef_create(odef_ctx** out, const odef_config* cfg) {
   if (cfg->diffusion != ODEF_DIFFUSION_DYNAMIC && cfg->diffusion != ODEF_DIFFUSION_FIXED)
     return fail(nullptr, "odef_create: unknown diffusion model %d", cfg->diffusion);
   if (cfg->n_traj <= 0) return fail(nullptr, "odef_create: n_traj must be positive");
+  if (cfg->rhs_id >= kJitFirstId && cfg->d * (cfg->order + 1) > 15)
+    return fail(nullptr, "odef_create: run-time compiled vector fields use the lane-per-trajectory kernels, state dimension d(q+1) <= 15 (got %d)", cfg->d * (cfg->order + 1));
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, "odef_create: no HIP device available (libodefilter_hip has no CPU path)");
@@ -272,6 +293,15 @@ int odef_create(odef_ctx** out, const odef_config* cfg) {
   build_prior(c->q, c->pc);
   c->team_path = (cfg->rhs_id == ODEF_RHS_PLEIADES);
   hipError_t e = hipSetDevice(c->device);
+  if (e == hipSuccess && cfg->rhs_id >= kJitFirstId) {
+    std::string jerr;
+    c->jit = jit_get_module(cfg->rhs_id, c->q, cfg->alg == ODEF_EK1, c->device, jerr);
+    if (!c->jit) {
+      fail(nullptr, "odef_create: %s", jerr.substr(0, 400).c_str());
+      delete c;
+      return -1;
+    }
+  }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
   for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev[k]);
   const size_t N = (size_t)cfg->n_traj;
@@ -512,7 +542,10 @@ int odef_solve_fixed(odef_ctx* c, const double* tgrid, int64_t n_t) {
     if ((size_t)c->TRI * (size_t)c->cfg.n_traj * sizeof(double) >= (1ull << 31))
       return fail(c, "odef_solve_fixed: n_traj * D(D+1)/2 * 8 bytes must stay below 2 GiB per save slot; shard the ensemble");
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    rc = launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 0, P, c->stream);
+    if (c->jit)
+      rc = jit_launch(P.everystep ? c->jit->fixed_every : c->jit->fixed_final, (unsigned)((P.N + 63) / 64), 1, &P, c->stream);
+    else
+      rc = launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 0, P, c->stream);
   }
   if (rc) return fail(c, "odef_solve_fixed: no kernel for rhs %d order %d", c->cfg.rhs_id, c->q);
   return finish_filter(c, 1);
@@ -549,7 +582,8 @@ int odef_solve_adaptive(odef_ctx* c, double t1, double abstol, double reltol, do
   }
   HIPCHK(c, hipMemsetAsync(c->f[ODEF_F_T].ptr, 0, c->f[ODEF_F_T].valid, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  const int rc = launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 1, P, c->stream);
+  const int rc = c->jit ? jit_launch(c->jit->adaptive, (unsigned)((P.N + 63) / 64), 1, &P, c->stream)
+                        : launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 1, P, c->stream);
   if (rc) return fail(c, "odef_solve_adaptive: no kernel for rhs %d order %d", c->cfg.rhs_id, c->q);
   return finish_filter(c, 1);
 }
@@ -584,7 +618,11 @@ int odef_smooth(odef_ctx* c) {
   }
   if (c->team_path && ensure_ws(c, (size_t)c->cfg.n_traj * team_smooth_ws_doubles(c->d, c->q))) return -1;
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  const int rc = c->team_path ? launch_smooth_d28(c->q, S, c->d_ws, c->stream) : launch_smooth(c->d, c->q, S, c->stream);
+  int rc;
+  if (c->jit)
+    rc = c->jit->posterior ? jit_launch(S.adaptive ? c->jit->smooth_adapt : c->jit->smooth_fixed, (unsigned)((S.N + 63) / 64), 1, &S, c->stream) : -3;
+  else
+    rc = c->team_path ? launch_smooth_d28(c->q, S, c->d_ws, c->stream) : launch_smooth(c->d, c->q, S, c->stream);
   if (rc) return fail(c, "odef_smooth: no kernel for d %d order %d", c->d, c->q);
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   HIPCHK(c, hipGetLastError());
@@ -634,7 +672,8 @@ int odef_dense_output(odef_ctx* c, const double* tq, int64_t n_q, int smoothed) 
   P.n_q = (long)n_q;
   P.qmean = (double*)c->f[ODEF_F_DENSE_MEAN].ptr;
   P.qcov = (double*)c->f[ODEF_F_DENSE_COV_TRIL].ptr;
-  const int rc = c->d == 2 ? launch_dense_d2(c->q, P, c->stream) : c->d == 3 ? launch_dense_d3(c->q, P, c->stream) : -3;
+  const int rc = c->jit ? (c->jit->posterior ? jit_launch(c->jit->dense, (unsigned)((P.N + 63) / 64), (unsigned)P.n_q, &P, c->stream) : -3)
+                 : c->d == 2 ? launch_dense_d2(c->q, P, c->stream) : c->d == 3 ? launch_dense_d3(c->q, P, c->stream) : -3;
   if (rc) return fail(c, "odef_dense_output: no kernel for d %d order %d", c->d, c->q);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -669,7 +708,8 @@ int odef_sample(odef_ctx* c, int64_t n_samples, uint64_t seed, double noise_scal
   S.noise_scale = noise_scale;
   S.samples = (double*)c->f[ODEF_F_SAMPLES].ptr;
   if (c->adaptive) HIPCHK(c, hipMemsetAsync(S.samples, 0, c->f[ODEF_F_SAMPLES].valid, c->stream));  // unused slots stay defined
-  const int rc = c->d == 2 ? launch_sample_d2(c->q, S, c->stream) : c->d == 3 ? launch_sample_d3(c->q, S, c->stream) : -3;
+  const int rc = c->jit ? (c->jit->posterior ? jit_launch(c->jit->sample, (unsigned)((S.N + 63) / 64), (unsigned)S.n_samples, &S, c->stream) : -3)
+                 : c->d == 2 ? launch_sample_d2(c->q, S, c->stream) : c->d == 3 ? launch_sample_d3(c->q, S, c->stream) : -3;
   if (rc) return fail(c, "odef_sample: no kernel for d %d order %d", c->d, c->q);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -1,0 +1,26 @@
+// Internal interface of the run-time compilation layer (jit.hip) used by the C-ABI layer (api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+namespace odef {
+
+constexpr int kJitFirstId = 100;  // rhs ids >= 100 are run-time compiled vector fields
+
+struct JitModule {
+  hipModule_t mod = nullptr;
+  hipFunction_t fixed_every = nullptr, fixed_final = nullptr, adaptive = nullptr;
+  hipFunction_t smooth_fixed = nullptr, smooth_adapt = nullptr, dense = nullptr, sample = nullptr;
+  bool posterior = false;  // smoother / dense output / sampler available (state dimension <= 12)
+};
+
+// returns the new rhs id (>= kJitFirstId) or -1 with the compiler log in `err`
+int jit_register(const char* name, const char* source, int d, int np, const char* include_dir, std::string& err);
+bool jit_lookup(int rhs_id, int* d, int* np);
+// compiles (once per (rhs, order, alg, device)) and loads the kernels on the CURRENT device
+JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& err);
+// one wavefront per block; params: pointer to the kernel's single by-value parameter struct
+int jit_launch(hipFunction_t f, unsigned gx, unsigned gy, const void* params, hipStream_t s);
+
+}  // namespace odef

@@ -1,0 +1,192 @@
+// Run-time compiled vector fields.
+// The reference calls a Julia closure f (and f.jac / ForwardDiff) in the middle of every step
+// (src/perform_step.jl:106,116-121).  A device kernel cannot call back into the host, so a user vector field is
+// handed over as SOURCE: a struct with the interface of the compiled-in registry (csrc/rhs.h) -- f generic in the
+// scalar type, so that the same text serves the step (double) and the Taylor-mode initialisation (truncated jets,
+// src/state_initialization.jl:2-53), plus the analytic Jacobian for EK1.  hiprtc compiles the very same lane
+// functions (ek_lane.h, smooth_lane.h, dense_lane.h, sample_lane.h) around it for gfx950; the kernels are loaded
+// with the module API and launched with the same parameter structs as the compiled-in ones.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "jit.h"
+
+namespace odef {
+namespace {
+
+struct JitRhs {
+  std::string name, source, include_dir;
+  int d, np;
+};
+
+std::mutex g_mu;
+std::vector<JitRhs> g_rhs;                                                      // id = kJitFirstId + index
+std::map<std::tuple<int, int, int, int>, std::unique_ptr<JitModule>> g_modules;  // (id, q, ek1, device)
+
+std::string default_include_dir() {
+  if (const char* e = getenv("ODEFILTER_HIP_INCLUDE")) return e;
+#ifdef ODEF_DEFAULT_CSRC
+  return ODEF_DEFAULT_CSRC;
+#else
+  return ".";
+#endif
+}
+
+std::string translation_unit(const JitRhs& r, int q, int ek1, bool with_posterior_kernels) {
+  const int D = r.d * (q + 1);
+  std::string s;
+  s += "#include \"ek_lane.h\"\n";
+  if (with_posterior_kernels) s += "#include \"smooth_lane.h\"\n#include \"dense_lane.h\"\n#include \"sample_lane.h\"\n";
+  s += "namespace odef {\n";
+  s += r.source;
+  s += "\nusing RhsJit = " + r.name + ";\n";
+  s += "static_assert(RhsJit::d == " + std::to_string(r.d) + ", \"d of the struct differs from the d passed to odef_rhs_compile\");\n";
+  s += "static_assert(RhsJit::np == " + std::to_string(r.np) + ", \"np of the struct differs from the n_params passed to odef_rhs_compile\");\n";
+  const std::string Q = std::to_string(q), EK = ek1 ? "true" : "false", DD = std::to_string(r.d);
+  s += "extern \"C\" __global__ __launch_bounds__(64) void odef_jit_fixed_every(const FilterParams P) {\n"
+       "  const long i0 = (long)blockIdx.x * 64;\n"
+       "  if (i0 + threadIdx.x < P.N) filter_fixed_lane<RhsJit, " + Q + ", " + EK + ", true>(P, i0, threadIdx.x);\n}\n";
+  s += "extern \"C\" __global__ __launch_bounds__(64) void odef_jit_fixed_final(const FilterParams P) {\n"
+       "  const long i0 = (long)blockIdx.x * 64;\n"
+       "  if (i0 + threadIdx.x < P.N) filter_fixed_lane<RhsJit, " + Q + ", " + EK + ", false>(P, i0, threadIdx.x);\n}\n";
+  s += "extern \"C\" __global__ __launch_bounds__(64) void odef_jit_adaptive(const FilterParams P) {\n"
+       "  const long i0 = (long)blockIdx.x * 64;\n"
+       "  if (i0 + threadIdx.x < P.N) filter_adaptive_lane<RhsJit, " + Q + ", " + EK + ">(P, i0, threadIdx.x);\n}\n";
+  if (with_posterior_kernels) {
+    const std::string TRI = std::to_string(D * (D + 1) / 2);
+    for (int adapt = 0; adapt < 2; ++adapt) {
+      s += std::string("extern \"C\" __global__ __launch_bounds__(64) void odef_jit_smooth_") + (adapt ? "adapt" : "fixed") +
+           "(const SmoothParams P) {\n"
+           "  __shared__ double lds[" + TRI + " * 64];\n"
+           "  const long i0 = (long)blockIdx.x * 64;\n"
+           "  const LaneMem xl{lds + threadIdx.x, 64};\n"
+           "  const bool valid = i0 + threadIdx.x < P.N;\n"
+           "  long n_hi = P.n_save;\n" +
+           (adapt ? "  n_hi = wave_uniform_max(valid ? (long)P.nsaved[i0 + threadIdx.x] : 0, valid);\n" : "") +
+           "  if (valid) smooth_lane_v2<" + DD + ", " + Q + ", " + (adapt ? "true" : "false") + ">(P, i0, threadIdx.x, xl, n_hi);\n}\n";
+    }
+    s += "extern \"C\" __global__ __launch_bounds__(64) void odef_jit_dense(const DenseParams P) {\n"
+         "  __shared__ double lds[" + TRI + " * 64];\n"
+         "  const long i = (long)blockIdx.x * 64 + threadIdx.x;\n"
+         "  const LaneMem xl{lds + threadIdx.x, 64};\n"
+         "  if (i < P.N) dense_lane<" + DD + ", " + Q + ">(P, i, (long)blockIdx.y, xl);\n}\n";
+    s += "extern \"C\" __global__ __launch_bounds__(64) void odef_jit_sample(const SampleParams P) {\n"
+         "  __shared__ double lds[" + TRI + " * 64];\n"
+         "  const long i = (long)blockIdx.x * 64 + threadIdx.x;\n"
+         "  const LaneMem xl{lds + threadIdx.x, 64};\n"
+         "  const bool valid = i < P.N;\n"
+         "  const long n_hi = P.adaptive ? wave_uniform_max(valid ? (long)P.nsaved[i] : 0, valid) : P.n_save;\n"
+         "  if (valid) sample_lane<" + DD + ", " + Q + ">(P, i, (long)blockIdx.y, xl, n_hi);\n}\n";
+  }
+  s += "}  // namespace odef\n";
+  return s;
+}
+
+// hiprtc compile -> code object; on failure `err` holds the compiler log
+bool compile(const std::string& src, const std::string& include_dir, std::vector<char>& code, std::string& err) {
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "odef_user_rhs.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    err = "hiprtcCreateProgram failed";
+    return false;
+  }
+  const std::string inc = "-I" + (include_dir.empty() ? default_include_dir() : include_dir);
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++20", inc.c_str()};
+  const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+  if (r != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n + 1, '\0');
+    if (n) hiprtcGetProgramLog(prog, &log[0]);
+    err = std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log.c_str();
+    hiprtcDestroyProgram(&prog);
+    return false;
+  }
+  size_t n = 0;
+  hiprtcGetCodeSize(prog, &n);
+  code.resize(n);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+  return true;
+}
+
+}  // namespace
+
+int jit_register(const char* name, const char* source, int d, int np, const char* include_dir, std::string& err) {
+  if (!name || !source || !*name) {
+    err = "odef_rhs_compile: null or empty name/source";
+    return -1;
+  }
+  if (d < 1 || d > 16 || np < 0) {
+    err = "odef_rhs_compile: d must be in 1..16 and n_params >= 0";
+    return -1;
+  }
+  JitRhs r{name, source, include_dir ? include_dir : "", d, np};
+  // compile the order-1 filter once now so that errors in the user's text surface here, with the compiler log
+  std::vector<char> code;
+  if (!compile(translation_unit(r, 1, 1, false), r.include_dir, code, err)) return -1;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_rhs.push_back(std::move(r));
+  return kJitFirstId + (int)g_rhs.size() - 1;
+}
+
+bool jit_lookup(int rhs_id, int* d, int* np) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int k = rhs_id - kJitFirstId;
+  if (k < 0 || k >= (int)g_rhs.size()) return false;
+  *d = g_rhs[k].d;
+  *np = g_rhs[k].np;
+  return true;
+}
+
+JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& err) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const int k = rhs_id - kJitFirstId;
+  if (k < 0 || k >= (int)g_rhs.size()) {
+    err = "unknown run-time rhs id";
+    return nullptr;
+  }
+  const auto key = std::make_tuple(rhs_id, q, ek1, device);
+  auto it = g_modules.find(key);
+  if (it != g_modules.end()) return it->second.get();
+  const JitRhs& r = g_rhs[k];
+  auto m = std::make_unique<JitModule>();
+  m->posterior = r.d * (q + 1) <= 12;  // the lane smoother / dense output / sampler keep a packed matrix per lane in LDS
+  std::vector<char> code;
+  if (!compile(translation_unit(r, q, ek1, m->posterior), r.include_dir, code, err)) return nullptr;
+  if (hipModuleLoadData(&m->mod, code.data()) != hipSuccess) {
+    err = "hipModuleLoadData failed for the run-time compiled vector field";
+    return nullptr;
+  }
+  struct { hipFunction_t* f; const char* name; bool need; } fn[] = {
+      {&m->fixed_every, "odef_jit_fixed_every", true},   {&m->fixed_final, "odef_jit_fixed_final", true},
+      {&m->adaptive, "odef_jit_adaptive", true},         {&m->smooth_fixed, "odef_jit_smooth_fixed", m->posterior},
+      {&m->smooth_adapt, "odef_jit_smooth_adapt", m->posterior}, {&m->dense, "odef_jit_dense", m->posterior},
+      {&m->sample, "odef_jit_sample", m->posterior}};
+  for (auto& e : fn) {
+    if (!e.need) continue;
+    if (hipModuleGetFunction(e.f, m->mod, e.name) != hipSuccess) {
+      err = std::string("kernel ") + e.name + " missing from the run-time compiled module";
+      (void)hipModuleUnload(m->mod);
+      return nullptr;
+    }
+  }
+  JitModule* out = m.get();
+  g_modules[key] = std::move(m);
+  return out;
+}
+
+int jit_launch(hipFunction_t f, unsigned gx, unsigned gy, const void* params, hipStream_t s) {
+  void* args[] = {const_cast<void*>(params)};
+  return hipModuleLaunchKernel(f, gx, gy, 1, 64, 1, 1, 0, s, args, nullptr) == hipSuccess ? 0 : -4;
+}
+
+}  // namespace odef

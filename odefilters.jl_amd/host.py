@@ -57,6 +57,7 @@ SYMBOLS = {
     "odef_version": (C.c_int, []),
     "odef_last_error": (C.c_char_p, [_vp]),
     "odef_create": (C.c_int, [C.POINTER(_vp), C.POINTER(OdefConfig)]),
+    "odef_rhs_compile": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.POINTER(C.c_int32)]),
     "odef_destroy": (None, [_vp]),
     "odef_set_stream": (C.c_int, [_vp, _vp]),
     "odef_set_problem": (C.c_int, [_vp, _dp, _dp, C.c_double]),
@@ -103,6 +104,23 @@ def load_library() -> C.CDLL:
 
 class OdefError(RuntimeError):
     pass
+
+
+def compile_rhs(name: str, source: str, d: int, n_params: int, struct_name: Optional[str] = None) -> str:
+    """Register a user vector field from HIP C++ source (`odef_rhs_compile`, include/odefilter.h): the stand-in for the
+    closure `f` (+ `jac`) the reference calls at src/perform_step.jl:106,116-121.  `source` defines a struct
+    `struct_name` (default: `name`) with the interface of csrc/rhs.h.  Afterwards `name` can be used wherever a
+    compiled-in vector field name is accepted (`ODEProblem(name, ...)`, `Context(name, ...)`).  Raises OdefError with
+    the compiler log when the text does not compile."""
+    lib = load_library()
+    rid = C.c_int32(-1)
+    inc = os.path.join(_HERE, "csrc").encode()
+    rc = lib.odef_rhs_compile((struct_name or name).encode(), source.encode(), int(d), int(n_params), inc, C.byref(rid))
+    if rc != 0:
+        raise OdefError(lib.odef_last_error(None).decode())
+    RHS[name] = int(rid.value)
+    RHS_DIMS[name] = (int(d), int(n_params))
+    return name
 
 
 def _as_dp(a: np.ndarray):

@@ -397,6 +397,118 @@ def test_sampling_needs_smoothing_solution(pkg):
         sol.sample(2)
 
 
+# ---- run-time compiled vector fields ------------------------------------------------------------------------
+
+USER_LORENZ = """
+struct UserLorenz {
+  static constexpr int d = 3, np = 3;
+  template <class T>
+  __device__ static void f(const T (&u)[3], const double* p, T (&du)[3]) {
+    const double s = p[0], r = p[1], b = p[2];
+    du[0] = s * (u[1] - u[0]);
+    du[1] = u[0] * (r - u[2]) - u[1];
+    du[2] = u[0] * u[1] - b * u[2];
+  }
+  __device__ static void jac(const double (&u)[3], const double* p, double (&J)[3][3]) {
+    const double s = p[0], r = p[1], b = p[2];
+    J[0][0] = -s;       J[0][1] = s;    J[0][2] = 0.0;
+    J[1][0] = r - u[2]; J[1][1] = -1.0; J[1][2] = -u[0];
+    J[2][0] = u[1];     J[2][1] = u[0]; J[2][2] = -b;
+  }
+};
+"""
+
+# Lorenz-96 with four variables: du_i = (u_{i+1} - u_{i-2}) u_{i-1} - u_i + F  (d = 4: no compiled-in kernel has it)
+USER_L96 = """
+struct UserL96 {
+  static constexpr int d = 4, np = 1;
+  template <class T>
+  __device__ static void f(const T (&u)[4], const double* p, T (&du)[4]) {
+    du[0] = (u[1] - u[2]) * u[3] - u[0] + p[0];
+    du[1] = (u[2] - u[3]) * u[0] - u[1] + p[0];
+    du[2] = (u[3] - u[0]) * u[1] - u[2] + p[0];
+    du[3] = (u[0] - u[1]) * u[2] - u[3] + p[0];
+  }
+  __device__ static void jac(const double (&u)[4], const double* p, double (&J)[4][4]) {
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) J[i][j] = 0.0;
+    for (int i = 0; i < 4; ++i) {
+      const int ip = (i + 1) % 4, im1 = (i + 3) % 4, im2 = (i + 2) % 4;
+      J[i][ip] += u[im1];
+      J[i][im2] -= u[im1];
+      J[i][im1] += u[ip] - u[im2];
+      J[i][i] -= 1.0;
+    }
+  }
+};
+"""
+
+
+def _l96_field():
+    def f(u, p, t):
+        return [(u[(i + 1) % 4] - u[(i + 2) % 4]) * u[(i + 3) % 4] - u[i] + p[0] for i in range(4)]
+
+    def jac(u, p, t):
+        J = np.zeros((4, 4))
+        for i in range(4):
+            ip, im1, im2 = (i + 1) % 4, (i + 3) % 4, (i + 2) % 4
+            J[i, ip] += u[im1]
+            J[i, im2] -= u[im1]
+            J[i, im1] += u[ip] - u[im2]
+            J[i, i] -= 1.0
+        return J
+
+    return orc.VectorField("l96", 100, 4, 1, f, jac, np.array([1.0, 2.0, 0.5, -1.0]), np.array([8.0]), (0.0, 0.25))
+
+
+def test_user_vector_field_equals_the_compiled_in_one(pkg):
+    """The same Lorenz-63 text through odef_rhs_compile (hiprtc) and through the compiled-in registry: identical
+    kernels source, so identical results -- fixed grid + smoother, adaptive, dense output, sampling."""
+    pkg.compile_rhs("UserLorenz", USER_LORENZ, 3, 3)
+    vf = orc.vector_field("lorenz63")
+    N = 70
+    for adaptive in (False, True):
+        sols = []
+        for rhs in ("lorenz63", "UserLorenz"):
+            ens = pkg.EnsembleProblem(pkg.ODEProblem(rhs, vf.u0, (0.0, 0.25), vf.p), perturb_scale=1e-2)
+            kw = dict(dt=2.0**-9, adaptive=True, max_steps=256) if adaptive else dict(dt=2.0**-7, adaptive=False)
+            sols.append(pkg.solve(ens, pkg.EK1(order=3), pkg.EnsembleHIP(), trajectories=N, **kw))
+        a, b = sols
+        assert b.retcode == ["Success"] * N
+        # same source, same compiler back end; tolerances only allow for a different contraction/scheduling choice
+        # (higher-derivative components amplify one ulp, tests/_parity.py)
+        np.testing.assert_allclose(b.x_filt_mean()[..., :3], a.x_filt_mean()[..., :3], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(b.x_smooth_mean()[..., :3], a.x_smooth_mean()[..., :3], rtol=1e-11, atol=0)
+        assert P.cov_err(b.x_smooth_cov()[0], a.x_smooth_cov()[0]) < 1e-6
+        np.testing.assert_array_equal(b.destats.naccept, a.destats.naccept)
+        tq = np.linspace(0.0, 0.25, 7)
+        np.testing.assert_allclose(b(tq)[0][..., :3], a(tq)[0][..., :3], rtol=1e-11, atol=0)
+        sa, sb = a.sample_states(3, 7)[:, :, :3], b.sample_states(3, 7)[:, :, :3]
+        assert np.abs(sb - sa).max() <= 1e-8 * np.abs(sa).max()
+
+
+@pytest.mark.parametrize("kind", ["EK0", "EK1"])
+def test_user_vector_field_new_dimension_against_oracle(pkg, kind):
+    """A vector field no compiled-in kernel covers (d = 4, order 2, D = 12): filter + smoother + dense output."""
+    pkg.compile_rhs("UserL96", USER_L96, 4, 1)
+    vf = _l96_field()
+    N, dt = 65, 2.0**-7
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("UserL96", vf.u0, vf.tspan, vf.p), perturb_scale=1e-2)
+    sol = pkg.solve(ens, _alg(pkg, kind, 2), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
+    assert sol.retcode == ["Success"] * N
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    consts = orc.make_consts(4, 2)
+    for i in (0, 64):
+        ref = orc.solve(vf, orc.Alg(kind, 2, "dynamic", True), u0=u0s[i], tspan=vf.tspan, dt=dt)
+        np.testing.assert_allclose(sol.x_filt_mean()[i][:, :4], ref.means(smoothed=False)[:, :4], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(sol.u[i], ref.u, rtol=1e-10, atol=1e-13)
+        assert P.cov_err(sol.x_smooth_cov()[i], ref.covs(smoothed=True)) < 1e-6
+        tq = np.array([0.01, 0.1, 0.2])
+        qm, _ = sol(tq)
+        want = np.array([orc.dense_output(ref, consts, float(t)).mu[:4] for t in tq])
+        np.testing.assert_allclose(qm[i][:, :4], want, rtol=1e-9, atol=1e-12)
+
+
 # ---- edge cases ------------------------------------------------------------------------------------------
 
 

@@ -41,3 +41,37 @@ def test_unpack_tril(pkg):
     M = M + M.T
     packed = np.array([M[i, j] for i in range(D) for j in range(i + 1)])
     np.testing.assert_array_equal(pkg.unpack_tril(packed[None], D)[0], M)
+
+
+USER_LORENZ = """
+struct UserLorenz {
+  static constexpr int d = 3, np = 3;
+  template <class T>
+  __device__ static void f(const T (&u)[3], const double* p, T (&du)[3]) {
+    const double s = p[0], r = p[1], b = p[2];
+    du[0] = s * (u[1] - u[0]);
+    du[1] = u[0] * (r - u[2]) - u[1];
+    du[2] = u[0] * u[1] - b * u[2];
+  }
+  __device__ static void jac(const double (&u)[3], const double* p, double (&J)[3][3]) {
+    const double s = p[0], r = p[1], b = p[2];
+    J[0][0] = -s;       J[0][1] = s;    J[0][2] = 0.0;
+    J[1][0] = r - u[2]; J[1][1] = -1.0; J[1][2] = -u[0];
+    J[2][0] = u[1];     J[2][1] = u[0]; J[2][2] = -b;
+  }
+};
+"""
+
+
+def test_user_vector_field_compiles_without_a_gpu(pkg):
+    """odef_rhs_compile: hiprtc cross-compiles the lane kernels around a user vector field for gfx950 (no GPU needed
+    to compile); a text that does not provide the interface is rejected with the compiler log."""
+    name = pkg.compile_rhs("UserLorenzCPU", USER_LORENZ, 3, 3, struct_name="UserLorenz")
+    import importlib
+
+    h = importlib.import_module(pkg.Context.__module__)
+    assert h.RHS[name] >= 100 and h.RHS_DIMS[name] == (3, 3)
+    with pytest.raises(pkg.OdefError, match="no member named 'f'"):
+        pkg.compile_rhs("Broken", "struct Broken { static constexpr int d = 2, np = 0; };", 2, 0)
+    with pytest.raises(pkg.OdefError, match="d of the struct differs"):
+        pkg.compile_rhs("WrongDim", USER_LORENZ.replace("UserLorenz", "WrongDim"), 2, 3)
