@@ -143,7 +143,8 @@ const char* odef_last_error(const odef_ctx* ctx); /* ctx may be NULL: last error
  *       static constexpr int d = 3, np = 3;
  *       template <class T>   // T = double in the step, a truncated Taylor jet in the initialisation
  *       __device__ static void f(const T (&u)[3], const double* p, T (&du)[3]) { ... }
- *       __device__ static void jac(const double (&u)[3], const double* p, double (&J)[3][3]) { ... }  // EK1
+ *       __device__ static void jac(const double (&u)[3], const double* p, double (&J)[3][3]) { ... }  // optional:
+ *           // without it EK1 differentiates f in forward mode (the reference's ForwardDiff fallback, :119-121)
  *     };
  *
  * hiprtc compiles the library's own lane kernels around it for gfx950 (include_dir = directory holding the csrc

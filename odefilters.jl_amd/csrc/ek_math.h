@@ -301,7 +301,7 @@ struct EKStep {
     double H0[d][d];
     if constexpr (IS_EK1) {
       double Jm[d][d];
-      RHS::jac(up, p, Jm);
+      rhs_jacobian<RHS>(up, p, Jm);  // f.jac, else forward-mode AD (src/perform_step.jl:116-121)
 #pragma unroll
       for (int r = 0; r < d; ++r)
 #pragma unroll

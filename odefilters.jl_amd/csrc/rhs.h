@@ -102,6 +102,116 @@ __device__ inline double inv_r3(double r2) { return 1.0 / (r2 * sqrt(r2)); }
 template <int NC>
 __device__ inline Jet<NC> inv_r3(const Jet<NC>& r2) { return jet_pow(r2, -1.5); }
 
+// ---- forward-mode dual numbers: the Jacobian of a vector field that provides no `jac` ----------------------
+// The reference falls back to ForwardDiff when `f.jac` is missing (src/perform_step.jl:119-121): exact
+// derivatives, one pass with d partials.  Same operator set as Jet.
+template <int ND>
+struct Dual {
+  double v;
+  double g[ND];
+  __device__ Dual() : v(0.0) {
+#pragma unroll
+    for (int k = 0; k < ND; ++k) g[k] = 0.0;
+  }
+  __device__ Dual(double x) : v(x) {
+#pragma unroll
+    for (int k = 0; k < ND; ++k) g[k] = 0.0;
+  }
+};
+#define ODEF_DUAL_LOOP for (int k = 0; k < ND; ++k)
+template <int ND>
+__device__ inline Dual<ND> operator+(const Dual<ND>& a, const Dual<ND>& b) {
+  Dual<ND> r;
+  r.v = a.v + b.v;
+#pragma unroll
+  ODEF_DUAL_LOOP r.g[k] = a.g[k] + b.g[k];
+  return r;
+}
+template <int ND>
+__device__ inline Dual<ND> operator-(const Dual<ND>& a, const Dual<ND>& b) {
+  Dual<ND> r;
+  r.v = a.v - b.v;
+#pragma unroll
+  ODEF_DUAL_LOOP r.g[k] = a.g[k] - b.g[k];
+  return r;
+}
+template <int ND>
+__device__ inline Dual<ND> operator-(const Dual<ND>& a) {
+  Dual<ND> r;
+  r.v = -a.v;
+#pragma unroll
+  ODEF_DUAL_LOOP r.g[k] = -a.g[k];
+  return r;
+}
+template <int ND>
+__device__ inline Dual<ND> operator*(const Dual<ND>& a, const Dual<ND>& b) {
+  Dual<ND> r;
+  r.v = a.v * b.v;
+#pragma unroll
+  ODEF_DUAL_LOOP r.g[k] = a.g[k] * b.v + a.v * b.g[k];
+  return r;
+}
+template <int ND>
+__device__ inline Dual<ND> operator*(double s, const Dual<ND>& a) {
+  Dual<ND> r;
+  r.v = s * a.v;
+#pragma unroll
+  ODEF_DUAL_LOOP r.g[k] = s * a.g[k];
+  return r;
+}
+template <int ND>
+__device__ inline Dual<ND> operator*(const Dual<ND>& a, double s) { return s * a; }
+template <int ND>
+__device__ inline Dual<ND> operator/(const Dual<ND>& a, double s) { return (1.0 / s) * a; }
+template <int ND>
+__device__ inline Dual<ND> operator+(const Dual<ND>& a, double s) { Dual<ND> r = a; r.v += s; return r; }
+template <int ND>
+__device__ inline Dual<ND> operator+(double s, const Dual<ND>& a) { return a + s; }
+template <int ND>
+__device__ inline Dual<ND> operator-(const Dual<ND>& a, double s) { Dual<ND> r = a; r.v -= s; return r; }
+template <int ND>
+__device__ inline Dual<ND> operator-(double s, const Dual<ND>& a) { Dual<ND> r = -a; r.v += s; return r; }
+template <int ND>
+__device__ inline Dual<ND> jet_pow(const Dual<ND>& x, double a) {
+  Dual<ND> r;
+  r.v = pow(x.v, a);
+  const double dv = a * pow(x.v, a - 1.0);
+#pragma unroll
+  ODEF_DUAL_LOOP r.g[k] = dv * x.g[k];
+  return r;
+}
+template <int ND>
+__device__ inline Dual<ND> inv_r3(const Dual<ND>& r2) { return jet_pow(r2, -1.5); }
+#undef ODEF_DUAL_LOOP
+
+template <class...>
+using odef_void_t = void;
+template <class RHS, class = void>
+struct HasJac { static constexpr bool value = false; };
+template <class RHS>
+struct HasJac<RHS, odef_void_t<decltype(&RHS::jac)>> { static constexpr bool value = true; };
+
+// J = df/du at u: the vector field's own `jac` when it has one, forward-mode differentiation of `f` otherwise
+template <class RHS>
+__device__ inline void rhs_jacobian(const double (&u)[RHS::d], const double* p, double (&J)[RHS::d][RHS::d]) {
+  constexpr int d = RHS::d;
+  if constexpr (HasJac<RHS>::value) {
+    RHS::jac(u, p, J);
+  } else {
+    Dual<d> ud[d], fd[d];
+#pragma unroll
+    for (int a = 0; a < d; ++a) {
+      ud[a] = Dual<d>(u[a]);
+      ud[a].g[a] = 1.0;
+    }
+    RHS::f(ud, p, fd);
+#pragma unroll
+    for (int r = 0; r < d; ++r)
+#pragma unroll
+      for (int a = 0; a < d; ++a) J[r][a] = fd[r].g[a];
+  }
+}
+
 // ---- the registry ----------------------------------------------------------------------
 // Optional: a vector field may provide `team_eval_pairs` / `team_eval_assemble` (see RhsPleiades) so that
 // the workgroup-per-trajectory kernels evaluate f and J with many threads instead of one.

@@ -487,6 +487,21 @@ def test_user_vector_field_equals_the_compiled_in_one(pkg):
         assert np.abs(sb - sa).max() <= 1e-8 * np.abs(sa).max()
 
 
+def test_user_vector_field_without_jacobian_uses_forward_mode(pkg):
+    """No `jac` in the struct: EK1 differentiates `f` with forward-mode duals, as the reference falls back to ForwardDiff
+    (src/perform_step.jl:119-121).  Exact derivatives, so the result matches the analytic-Jacobian kernel."""
+    src = USER_LORENZ[: USER_LORENZ.index("  __device__ static void jac")] + "};\n"
+    pkg.compile_rhs("LorenzNoJac", src.replace("UserLorenz", "LorenzNoJac"), 3, 3)
+    vf = orc.vector_field("lorenz63")
+    sols = []
+    for rhs in ("lorenz63", "LorenzNoJac"):
+        prob = pkg.ODEProblem(rhs, vf.u0, (0.0, 0.5), vf.p)
+        sols.append(pkg.solve(prob, pkg.EK1(order=3), dt=2.0**-7, adaptive=False))
+    np.testing.assert_allclose(sols[1].u, sols[0].u, rtol=1e-11, atol=0)
+    ref = orc.solve(vf, orc.EK1(order=3), tspan=(0.0, 0.5), dt=2.0**-7)
+    np.testing.assert_allclose(sols[1].u[0], ref.u, rtol=1e-10, atol=0)
+
+
 @pytest.mark.parametrize("kind", ["EK0", "EK1"])
 def test_user_vector_field_new_dimension_against_oracle(pkg, kind):
     """A vector field no compiled-in kernel covers (d = 4, order 2, D = 12): filter + smoother + dense output."""
