@@ -66,7 +66,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--traj", type=int, default=65536, help="trajectories per GPU")
+    ap.add_argument("--traj", type=int, default=65536, help="trajectories per GPU (weak scaling, the default)")
+    ap.add_argument("--total-traj", type=int, default=0,
+                    help="strong scaling instead: this many trajectories in total, split evenly over the ranks")
     ap.add_argument("--nsteps", type=int, default=1024, help="solver steps per trajectory (tspan = nsteps * 2^-9)")
     ap.add_argument("--save", choices=["everystep", "final"], default="everystep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,6 +89,10 @@ def main():
     D = d * (q + 1)
     TRI = D * (D + 1) // 2
     N, nsteps = args.traj, args.nsteps
+    if args.total_traj:
+        if args.total_traj % world:
+            raise SystemExit("--total-traj must be divisible by the number of ranks")
+        N = args.total_traj // world
     everystep = args.save == "everystep"
     n_save = nsteps + 1 if everystep else 1
     dt = 2.0**-9
@@ -159,7 +165,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_traj else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",

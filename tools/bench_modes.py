@@ -50,3 +50,15 @@ if "pleiades" in args.modes.split(","):
     print(json.dumps({"mode": "pleiades", "traj": N, "nsteps": nsp, "filter_ms": f_ms, "steps_per_s": N * nsp / (f_ms * 1e-3),
                       "F_alg_TFLOPs": F_alg * N * nsp / (f_ms * 1e-3) / 1e12, "retcodes_ok": bool((ctx.get(10) == 0).all())}))
     ctx.close()
+if "pleiades_smooth" in args.modes.split(","):
+    u0 = [3.0, 3.0, -1.0, -3.0, 2.0, -2.0, 2.0, 3.0, -3.0, 2.0, 0.0, 0.0, -4.0, 4.0,
+          0.0, 0.0, 0.0, 0.0, 0.0, 1.75, -1.5, 0.0, 0.0, 0.0, -1.25, 1.0, 0.0, 0.0]
+    nsp = min(ns, 64)
+    ctx = pkg.Context("pleiades", 5, 1, N, smooth=True)
+    ctx.set_problem_perturbed(u0, [], 0.0, 1e-3, n_perturbed=14)
+    for _ in range(2):
+        ctx.solve_fixed(np.arange(nsp + 1) * 2.0**-10); ctx.smooth()
+    f_ms, s_ms = ctx.kernel_time_ms(0)[0], ctx.kernel_time_ms(1)[0]
+    print(json.dumps({"mode": "pleiades_smooth", "traj": N, "nsteps": nsp, "filter_everystep_ms": f_ms, "smooth_ms": s_ms,
+                      "filter_steps_per_s": N * nsp / (f_ms * 1e-3), "smoother_steps_per_s": N * (nsp - 1) / (s_ms * 1e-3)}))
+    ctx.close()
