@@ -2,6 +2,7 @@
 // (256 CUs x 4 SIMDs = 1024 wave slots at one wave per SIMD: 65 536 trajectories fill the
 // chip exactly once; block size 64 lets the dispatcher spread waves over all SIMDs.)
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include "dispatch.h"
 #include "smooth_team.h"
@@ -51,6 +52,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_num_vgpr(128))) void r
 // Smoother, one lane per trajectory (D <= 12): the read-only filter covariance of the step sits in
 // lane-private LDS (78 doubles x 64 lanes = 39 KB per wave at D = 12), everything else in registers.
 constexpr int kSmoothLaneMaxD = 12;
+// Ensemble size from which the lane kernel is used.  Measured on Lorenz EK1(3), 1 023 steps: N = 2 048 / 4 096:
+// 27.6 / 27.7 ms (lane) against 13.9 / 15.5 ms (row teams); N = 16 384: 30.4 against 42.4 ms.
+// ODEF_SMOOTH_LANE_MIN_N overrides it (read at every launch, so tests can exercise both kernels).
+constexpr long kSmoothLaneMinN = 6144;
+inline long smooth_lane_min_n() {
+  const char* e = getenv("ODEF_SMOOTH_LANE_MIN_N");
+  return e ? atol(e) : kSmoothLaneMinN;
+}
 // Two kernels (fixed grid / adaptive records) so that each gets its own register allocation.
 template <int d, int q, bool ADAPT>
 __global__ __launch_bounds__(kWave) void rts_smooth_lane_kernel(const SmoothParams P) {
@@ -184,17 +193,24 @@ struct LaunchSmooth {
   hipStream_t s;
   template <int d, int q>
   void operator()() {
+    constexpr int TPB = kWave / SmoothTeam<d * (q + 1)>::lanes;
+    // Small state AND a large ensemble: one lane per trajectory.  A small ensemble does not fill the chip that
+    // way (N / 64 wavefronts for 1 024 SIMDs); the row-per-lane team kernel gives TPB x fewer trajectories per
+    // wavefront, i.e. more wavefronts, and wins below kSmoothLaneMinN.
+    bool lane_kernel = false;
+    if constexpr (d * (q + 1) <= kSmoothLaneMaxD) lane_kernel = P.N >= smooth_lane_min_n();
     if constexpr (d * (q + 1) <= kSmoothLaneMaxD) {
-      const unsigned grid = (unsigned)((P.N + kWave - 1) / kWave);
-      if (P.adaptive)
-        hipLaunchKernelGGL((rts_smooth_lane_kernel<d, q, true>), dim3(grid), dim3(kWave), 0, s, P);
-      else
-        hipLaunchKernelGGL((rts_smooth_lane_kernel<d, q, false>), dim3(grid), dim3(kWave), 0, s, P);
-    } else {
-      constexpr int TPB = kWave / SmoothTeam<d * (q + 1)>::lanes;
-      const unsigned grid = (unsigned)((P.N + TPB - 1) / TPB);
-      hipLaunchKernelGGL((rts_smooth_kernel<d, q>), dim3(grid), dim3(kWave), 0, s, P);
+      if (lane_kernel) {
+        const unsigned grid = (unsigned)((P.N + kWave - 1) / kWave);
+        if (P.adaptive)
+          hipLaunchKernelGGL((rts_smooth_lane_kernel<d, q, true>), dim3(grid), dim3(kWave), 0, s, P);
+        else
+          hipLaunchKernelGGL((rts_smooth_lane_kernel<d, q, false>), dim3(grid), dim3(kWave), 0, s, P);
+        return;
+      }
     }
+    const unsigned grid = (unsigned)((P.N + TPB - 1) / TPB);
+    hipLaunchKernelGGL((rts_smooth_kernel<d, q>), dim3(grid), dim3(kWave), 0, s, P);
   }
 };
 

@@ -99,6 +99,31 @@ def test_ensemble_parity_with_oracle(pkg, rhs, kind, q, dt, t1):
                                    f"{rhs} {kind}({q}) traj {i} smoothed={smoothed}")
 
 
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_both_small_state_smoothers_against_oracle(pkg, adaptive, monkeypatch):
+    """D <= 12 has two smoother kernels, chosen by ensemble size (lane-per-trajectory for large ensembles, row-per-lane
+    teams for small ones, csrc/ek_kernels.h kSmoothLaneMinN); ODEF_SMOOTH_LANE_MIN_N forces each in turn."""
+    vf = orc.vector_field("lorenz63")
+    N, t1 = 130, 0.5
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, (0.0, t1), vf.p), perturb_scale=1e-2)
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    kw = dict(dt=2.0**-9, adaptive=True, max_steps=256) if adaptive else dict(dt=2.0**-7, adaptive=False)
+    sols = {}
+    for name, min_n in (("lane", "1"), ("rows", "1000000000")):
+        monkeypatch.setenv("ODEF_SMOOTH_LANE_MIN_N", min_n)
+        sols[name] = pkg.solve(ens, pkg.EK1(order=3), pkg.EnsembleHIP(), trajectories=N, **kw)
+        assert sols[name].retcode == ["Success"] * N
+        _ = sols[name].x_smooth_mean()  # fetch while the override is in place (lazy accessors)
+    for i in (0, 64, 129):
+        ref = orc.solve(vf, orc.EK1(order=3), u0=u0s[i], tspan=(0.0, t1), **({"dt": 2.0**-9, "adaptive": True} if adaptive else {"dt": 2.0**-7}))
+        n = len(ref.t)
+        for name in ("lane", "rows"):
+            m, c = sols[name].x_smooth_mean()[i][:n], sols[name].x_smooth_cov()[i][:n]
+            np.testing.assert_allclose(m[:, :3], ref.means(smoothed=True)[:, :3], rtol=1e-7 if adaptive else 1e-10, err_msg=name)
+            assert P.cov_err(c, ref.covs(smoothed=True)) < 1e-5, name
+    np.testing.assert_allclose(sols["rows"].x_smooth_mean()[..., :3], sols["lane"].x_smooth_mean()[..., :3], rtol=1e-9, atol=1e-12)
+
+
 def test_per_trajectory_parameters(pkg):
     vf = orc.vector_field("lotka_volterra")
     N = 70
