@@ -461,13 +461,17 @@ class EnsembleSolution:
     def _order(self):
         """(order [N, n_save], count [N]): per trajectory the record indices with the kept ones first."""
         if "_order" not in self._cache:
-            tt = self._get(F_T).T
+            tt = self._tsave()
             ns = self._get(F_NSAVED)
             idx = np.arange(tt.shape[1])[None, :]
             keep = idx < ns[:, None]
             keep[:, 1:] &= tt[:, 1:] != tt[:, :-1]
             self._cache["_order"] = (np.argsort(~keep, axis=1, kind="stable"), keep.sum(axis=1).astype(np.int32))
         return self._cache["_order"]
+
+    def _tsave(self) -> np.ndarray:
+        """Adaptive solves: the per-trajectory save times [N, n_save] (also for N = 1)."""
+        return self._get(F_T).reshape(self.ctx.n_save, self.ctx.N).T
 
     def raw_index(self, i: int) -> np.ndarray:
         """Device record index of every kept record of trajectory i (identity for fixed grids)."""
@@ -487,8 +491,8 @@ class EnsembleSolution:
 
     @property
     def t(self) -> np.ndarray:
-        t = self._get(F_T)
-        return self._compact(t.T) if t.ndim == 2 else t
+        """Fixed grid: [n_save] (shared by all trajectories); adaptive: [N, n_save], zero-padded."""
+        return self._compact(self._tsave()) if self.adaptive else self._get(F_T).reshape(-1)
 
     @property
     def nsaved(self) -> np.ndarray:

@@ -549,6 +549,54 @@ def test_user_vector_field_new_dimension_against_oracle(pkg, kind):
         np.testing.assert_allclose(qm[i][:, :4], want, rtol=1e-9, atol=1e-12)
 
 
+# ---- the reference's "specific problems" (test/specific_problems.jl) -------------------------------------------
+
+USER_LOGISTIC = """
+struct Logistic {
+  static constexpr int d = 1, np = 1;
+  template <class T>
+  __device__ static void f(const T (&u)[1], const double* p, T (&du)[1]) { du[0] = p[0] * u[0] * (1.0 - u[0]); }
+};
+"""
+
+
+@pytest.mark.parametrize("kind", ["EK0", "EK1"])
+def test_one_dimensional_problem(pkg, kind):
+    """test/specific_problems.jl:70-75 (OOP logistic problem, d = 1, order 4, default adaptive solve); EK1 differentiates
+    f in forward mode.  A run-time compiled vector field: no compiled-in kernel has d = 1."""
+    pkg.compile_rhs("Logistic", USER_LOGISTIC, 1, 1)
+    f = lambda u, p, t: [p[0] * u[0] * (1.0 - u[0])]  # noqa: E731
+    jac = lambda u, p, t: np.array([[p[0] * (1.0 - 2.0 * u[0])]])  # noqa: E731
+    vf = orc.VectorField("logistic", 100, 1, 1, f, jac, np.array([0.1]), np.array([3.0]), (0.0, 5.0))
+    prob = pkg.ODEProblem("Logistic", vf.u0, vf.tspan, vf.p)
+    sol = pkg.solve(prob, _alg(pkg, kind, 4), adaptive=True, dt=5e-3, max_steps=1024)
+    assert sol.retcode == ["Success"]
+    ref = orc.solve(vf, orc.Alg(kind, 4, "dynamic", True), adaptive=True, dt=5e-3)
+    n = int(sol.nsaved[0])
+    assert n == len(ref.t)
+    # the step sizes come out of a 4th root of an error estimate that is itself at rounding level relative to the state:
+    # same accept/reject sequence, times equal to ~1e-7
+    np.testing.assert_allclose(sol.t[0, :n], ref.t, rtol=1e-5)
+    np.testing.assert_allclose(sol.u[0, :n], ref.u, rtol=1e-5)
+    exact = 0.1 * np.exp(15.0) / (1.0 + 0.1 * (np.exp(15.0) - 1.0))
+    assert abs(sol.u[0, n - 1, 0] - exact) < 1e-4
+
+
+def test_stiff_vanderpol(pkg):
+    """test/specific_problems.jl:44-47: the stiff van der Pol problem runs through the adaptive EK1(3) (mu = 1e3 here, so
+    that the oracle finishes in a second: 3 700 accepted steps)."""
+    vf = orc.vector_field("vanderpol")
+    p = np.array([1e3])
+    prob = pkg.ODEProblem("vanderpol", vf.u0, (0.0, 6.3), p)
+    sol = pkg.solve(prob, pkg.EK1(order=3, smooth=False), adaptive=True, dt=1e-3, max_steps=8192)
+    assert sol.retcode == ["Success"]
+    ref = orc.solve(vf, orc.EK1(order=3, smooth=False), p=p, tspan=(0.0, 6.3), adaptive=True, dt=1e-3)
+    n = int(sol.nsaved[0])
+    assert abs(n - len(ref.t)) <= 0.02 * len(ref.t)  # the accept/reject sequence of a stiff problem may differ by rounding
+    assert sol.t[0, n - 1] == 6.3
+    np.testing.assert_allclose(sol.u[0, n - 1], ref.u[-1], rtol=1e-3)
+
+
 # ---- edge cases ------------------------------------------------------------------------------------------
 
 
