@@ -29,6 +29,34 @@ __global__ __launch_bounds__(64) void k_store(double* out, long N, int rows, int
   }
 }
 
+// Blocked layout [nsteps][N/64][rows][64]: the record of one wavefront (rows x 512 B) is one contiguous block.
+template <int NT>
+__global__ __launch_bounds__(64) void k_store_blocked(double* out, long N, int rows, int nsteps) {
+  const long grp = blockIdx.x, G = N / 64;
+  const unsigned lane = threadIdx.x;
+  double v = (double)lane;
+  for (int n = 0; n < nsteps; ++n) {
+    double* base = out + (((size_t)n * G + grp) * rows) * 64;
+    for (int k = 0; k < rows; ++k) {
+      if (NT) __builtin_nontemporal_store(v, base + lane); else base[lane] = v;
+      base += 64;
+    }
+    v += 1.0;
+  }
+}
+template <int NT>
+float run_blocked(double* d, long N, int rows, int nsteps) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  float best = 1e9;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((k_store_blocked<NT>), dim3(N / 64), dim3(64), 0, 0, d, N, rows, nsteps);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+  }
+  return best;
+}
+
 template <int W, int NT>
 float run(double* d, long N, int rows, int nsteps, int split) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -46,6 +74,11 @@ int main(int argc, char** argv) {
   const long N = 65536; const int rows = 96, nsteps = argc > 1 ? atoi(argv[1]) : 512;
   double* d; size_t bytes = (size_t)nsteps * rows * N * 8;
   CK(hipMalloc((void**)&d, bytes));
+  {
+    float t;
+    t = run_blocked<0>(d, N, rows, nsteps); printf("blocked layout, 1 wave/SIMD, 8 B/lane plain  %.3f ms %.2f TB/s\n", t, bytes / (t * 1e-3) / 1e12);
+    t = run_blocked<1>(d, N, rows, nsteps); printf("blocked layout, 1 wave/SIMD, 8 B/lane nt     %.3f ms %.2f TB/s\n", t, bytes / (t * 1e-3) / 1e12);
+  }
   for (int split : {1, 2, 4, 8}) {
     float t;
     t = run<1, 0>(d, N, rows, nsteps, split); printf("waves/SIMD=%d  8 B/lane plain  %.3f ms %.2f TB/s\n", split, t, bytes / (t * 1e-3) / 1e12);
