@@ -178,7 +178,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "traffic": traffic,
-                "kernel": "ek_filter_fixed_kernel<RhsLorenz63,3,true,true>", "kernel_ms": k_ms,
+                "kernel": "ek_filter_fixed_kernel<RhsLorenz63,3,true,%s>" % ("true" if everystep else "false"), "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
             "parity_ok": ok,
