@@ -42,7 +42,11 @@ __device__ inline unsigned long long splitmix64_dev(unsigned long long x) {
 __device__ inline double sample_normal(unsigned long long seed, unsigned long long c) {
   const double u1 = (double)(splitmix64_dev(seed + 2ull * c) >> 11) * 0x1.0p-53;
   const double u2 = (double)(splitmix64_dev(seed + 2ull * c + 1ull) >> 11) * 0x1.0p-53;
+#ifdef ODEF_HOST_EMUL
   return sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586 * u2);
+#else
+  return sqrt(-2.0 * log(1.0 - u1)) * cospi(2.0 * u2);  // same value to rounding, without cos()'s large-argument reduction code
+#endif
 }
 
 // out = m + scale * L xi, L = lower factor of the packed covariance C (destroyed)
@@ -109,14 +113,30 @@ __device__ inline void sample_lane(const SampleParams& P, long i, long j, const 
       continue;
     }
     const double sigma2 = P.diff[(size_t)(s + 1) * N + i];
+    // all loads of the step first, arithmetic afterwards (see smooth_lane_v2)
     double mt[D], B[TRI], Cs[TRI], msn[D], mc[D];
+    {
+      const double* pc_ = P.cov + ((size_t)s * TRI) * N + i;
+      const double* pm_ = P.mean + ((size_t)s * D) * N + i;
 #pragma unroll
-    for (int k = 0; k < D; ++k) mt[k] = pj[k / d] * P.mean[((size_t)s * D + k) * N + i];
+      for (int k = 0; k < TRI; ++k) {
+        B[k] = *pc_;
+        pc_ += N;
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        mt[k] = *pm_;
+        pm_ += N;
+      }
+    }
+    ODEF_SCHED_FENCE();
+#pragma unroll
+    for (int k = 0; k < D; ++k) mt[k] *= pj[k / d];
 #pragma unroll
     for (int a = 0; a < D; ++a)
 #pragma unroll
       for (int b = 0; b <= a; ++b) {
-        const double x = P.cov[((size_t)s * TRI + tri(a, b)) * N + i] * (pj[a / d] * pj[b / d]);
+        const double x = B[tri(a, b)] * (pj[a / d] * pj[b / d]);
         xl.set(tri(a, b), x);
         B[tri(a, b)] = x;
         Cs[tri(a, b)] = 0.0;  // Gaussian(sample, 0) (src/solution_sampling.jl:52)

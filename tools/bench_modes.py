@@ -62,3 +62,17 @@ if "pleiades_smooth" in args.modes.split(","):
     print(json.dumps({"mode": "pleiades_smooth", "traj": N, "nsteps": nsp, "filter_everystep_ms": f_ms, "smooth_ms": s_ms,
                       "filter_steps_per_s": N * nsp / (f_ms * 1e-3), "smoother_steps_per_s": N * (nsp - 1) / (s_ms * 1e-3)}))
     ctx.close()
+if "sample" in args.modes.split(","):
+    nsp = min(ns, 256)
+    ctx = pkg.Context("lorenz63", 3, 1, N, smooth=True)
+    ctx.set_problem_perturbed([1.0, 0.0, 0.0], [10.0, 28.0, 8.0 / 3.0], 0.0, 1e-2)
+    ctx.solve_fixed(np.arange(nsp + 1) * dt); ctx.smooth()
+    nsmp = 4
+    import ctypes
+    for _ in range(2):
+        t0 = time.perf_counter()
+        ctx._chk(ctx.lib.odef_sample(ctx._h, nsmp, 7, 1.0))
+        el = time.perf_counter() - t0
+    print(json.dumps({"mode": "sample", "traj": N, "nsteps": nsp, "n_samples": nsmp, "wall_ms": el * 1e3,
+                      "sample_steps_per_s": N * nsmp * nsp / el, "smooth_ms": ctx.kernel_time_ms(1)[0]}))
+    ctx.close()
