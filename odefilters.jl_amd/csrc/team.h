@@ -137,6 +137,76 @@ __device__ inline void team_solve_right_spd(const Team<TEAM>& t, const double* _
   }
 }
 
+// In-place transpose of a full-storage square matrix.
+template <int D, int TEAM>
+__device__ inline void team_transpose_inplace(const Team<TEAM>& t, double* __restrict__ X) {
+  constexpr int LD = team_ld(D);
+  ODEF_TEAM_FOR(e, D * D) {
+    const int r = e / D, c = e % D;
+    if (c < r) {
+      const double a = X[r * LD + c], b = X[c * LD + r];
+      X[r * LD + c] = b;
+      X[c * LD + r] = a;
+    }
+  }
+}
+
+// Columns of GT solve (L L') GT = YT in place, one thread per COLUMN: thread r touches GT[k][r], so the threads of a
+// wavefront read consecutive addresses (the row-parallel form above streams a private row per lane: 64 cache lines per
+// load instruction).  Same arithmetic per right-hand side as team_solve_right_spd.
+template <int D, int TEAM>
+__device__ inline void team_solve_spd_columns(const Team<TEAM>& t, const double* __restrict__ L, double* __restrict__ GT) {
+  constexpr int LD = team_ld(D);
+  ODEF_TEAM_FOR(r, D) {
+    for (int k = 0; k < D; ++k) {
+      double s = GT[k * LD + r];
+      for (int c = 0; c < k; ++c) s -= L[k * LD + c] * GT[c * LD + r];
+      const double lkk = L[k * LD + k];
+      GT[k * LD + r] = (lkk != 0.0) ? s / lkk : 0.0;
+    }
+    for (int k = D - 1; k >= 0; --k) {
+      double s = GT[k * LD + r];
+      for (int c = k + 1; c < D; ++c) s -= L[c * LD + k] * GT[c * LD + r];
+      const double lkk = L[k * LD + k];
+      GT[k * LD + r] = (lkk != 0.0) ? s / lkk : 0.0;
+    }
+  }
+}
+
+// C = op(A) B with a 4 x 4 block of C per thread (full-storage D x D matrices in global memory, D % 4 == 0):
+// op(A) = A' when A_TRANSPOSED (A is given as its transpose).  Per k the thread loads 4 + 4 values for 16 FMAs;
+// consecutive threads take consecutive column blocks, so the B loads of a wavefront are one contiguous 2 KB run and
+// the A loads are wave-uniform.
+template <int D, int TEAM, bool A_TRANSPOSED>
+__device__ inline void team_gemm_blocked(const Team<TEAM>& t, const double* __restrict__ A, const double* __restrict__ B,
+                                         double* __restrict__ C) {
+  constexpr int LD = team_ld(D), BS = 4, NBK = D / BS;
+  static_assert(D % BS == 0, "block size must divide the state dimension");
+  ODEF_TEAM_FOR(blk, NBK * NBK) {
+    const int r0 = (blk / NBK) * BS, c0 = (blk % NBK) * BS;
+    double acc[BS][BS];
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) acc[i][j] = 0.0;
+    for (int k = 0; k < D; ++k) {
+      double a[BS], b[BS];
+#pragma unroll
+      for (int i = 0; i < BS; ++i) a[i] = A_TRANSPOSED ? A[k * LD + r0 + i] : A[(r0 + i) * LD + k];
+#pragma unroll
+      for (int j = 0; j < BS; ++j) b[j] = B[k * LD + c0 + j];
+#pragma unroll
+      for (int i = 0; i < BS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) acc[i][j] += a[i] * b[j];
+    }
+#pragma unroll
+    for (int i = 0; i < BS; ++i)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) C[(r0 + i) * LD + c0 + j] = acc[i][j];
+  }
+}
+
 // One Rauch-Tung-Striebel step for one trajectory (src/smoothing.jl:31-63, src/filtering.jl:136-154).
 // Workspace `ws` (SmoothWs::size doubles): X | Y/G | M | vectors.  On entry X holds the filter covariance
 // of time i (full symmetric, un-preconditioned), `mf` its mean, M / `ms` the smoothed covariance /
@@ -151,7 +221,7 @@ __device__ inline void team_solve_right_spd(const Team<TEAM>& t, const double* _
 template <int d, int NB>
 struct SmoothWs {
   static constexpr int D = d * NB, LD = team_ld(D), MAT = D * LD;
-  static constexpr int X = 0, Y = MAT, M = 2 * MAT, MF = 3 * MAT, MS = MF + D, MP = MS + D, DL = MP + D, used = DL + D;
+  static constexpr int X = 0, Y = MAT, M = 2 * MAT, MF = 3 * MAT, MS = MF + D, MP = MS + D, DL = MP + D, COL = DL + D, used = COL + D;
   // per-team stride: == 8 (mod 32) doubles, so the 4 teams of a wavefront start 16 banks apart
   static constexpr int size = used + ((8 - used % 32) + 32) % 32;
 };
@@ -201,6 +271,24 @@ __device__ inline void team_smooth_step(const Team<TEAM>& t, const PriorConsts& 
   }
   ODEF_TEAM_FOR(i, D) dl[i] = ms[i] - mp[i];
   t.sync();
+  if constexpr (D > 32) {  // (on the device: TEAM = 256; the host emulation runs the same branch with TEAM = 1)
+    // Whole-workgroup team on matrices in global memory: everything below runs on G' (Y transposed in place), so
+    // that consecutive threads always touch consecutive addresses.
+    team_transpose_inplace<D, TEAM>(t, Y);
+    team_cholesky_coalesced<D, TEAM>(t, X, D, ws + W::COL);
+    team_solve_spd_columns<D, TEAM>(t, X, Y);  // Y = G'
+    t.sync();
+    ODEF_TEAM_FOR(i, D) {
+      double s = mf[i];
+      for (int k = 0; k < D; ++k) s += Y[k * LD + i] * dl[k];
+      ms[i] = s * tab[kTabPIJ + i / d];  // un-precondition (src/smoothing.jl:26)
+    }
+    team_gemm_blocked<D, TEAM, true>(t, Y, M, X);   // T = G M
+    t.sync();
+    team_gemm_blocked<D, TEAM, false>(t, X, Y, M);  // M <- T G'
+    t.sync();
+    return;
+  }
   team_cholesky<D, TEAM>(t, X, D);
   // G = Y (Sigma^-)^-1, rows in place in Y  (src/smoothing.jl:42-43)
   team_solve_right_spd<D, TEAM>(t, X, Y);
