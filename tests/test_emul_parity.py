@@ -116,6 +116,21 @@ def test_pleiades_team_filter(q, ek1, path):
         assert P.cov_err(r["cov"][0], sol.covs(smoothed=False)) < 1e-6
 
 
+@pytest.mark.parametrize("ek1", [True, False])
+def test_pleiades_fixed_diffusion_tiles(ek1):
+    """FixedDiffusion (src/diffusions.jl:11-36, static order of src/perform_step.jl:56-63) on the tiled path: the
+    running mean of z'S^-1 z / d is kept by the helper wavefront."""
+    vf = orc.vector_field("pleiades")
+    alg = orc.Alg("EK1" if ek1 else "EK0", 2, "fixed", False)
+    ns = 8
+    sol = orc.solve(vf, alg, dt=2.0**-10, tspan=(0.0, ns * 2.0**-10))
+    r = E.emul_solve(vf.rhs_id, 28, 2, ek1, vf.u0[None, :], vf.p, team="tiles", tgrid=np.array(sol.t), fixed_diffusion=True)
+    np.testing.assert_allclose(r["mean"][0][:, :28], sol.means(smoothed=False)[:, :28], rtol=1e-12, atol=1e-13)
+    # the kernel records the running mean per step; the reference overwrites all entries with the final value in its
+    # postamble (src/integrator_utils.jl:4-18), which the library does in a separate rescale pass
+    np.testing.assert_allclose(r["diff"][0][-1], sol.diffusions[-1], rtol=1e-9)
+
+
 @pytest.mark.parametrize("q", [4, 5])
 def test_rows_smoother_larger_state(q):
     """D = 15 / 18 (Lorenz, order 4 / 5): the row-per-lane team smoother (smooth_rows.h, 16- and 32-lane teams)."""

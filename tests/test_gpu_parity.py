@@ -296,6 +296,20 @@ def test_pleiades_adaptive_is_rejected_loudly(pkg):
         pkg.solve(prob, pkg.EK1(order=3), pkg.EnsembleHIP(), adaptive=True, dt=1e-3)
 
 
+def test_pleiades_fixed_diffusion(pkg):
+    """FixedDiffusion on the workgroup-per-trajectory path (tiled filter + helper wavefront, post-hoc covariance rescale,
+    team smoother): src/diffusions.jl:11-36, src/integrator_utils.jl:4-18."""
+    vf = orc.vector_field("pleiades")
+    ns, dt = 8, 2.0**-10
+    prob = pkg.ODEProblem("pleiades", vf.u0, (0.0, ns * dt), ())
+    sol = pkg.solve(prob, pkg.EK1(order=2, diffusionmodel="fixed"), dt=dt, adaptive=False)
+    ref = orc.solve(vf, orc.Alg("EK1", 2, "fixed", True), dt=dt, tspan=(0.0, ns * dt))
+    np.testing.assert_allclose(sol.u[0], ref.u, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(sol.diffusions[0], ref.diffusions, rtol=1e-8)
+    assert P.cov_err(sol.x_filt_cov()[0], ref.covs(smoothed=False)) < 1e-6
+    assert P.cov_err(sol.x_smooth_cov()[0], ref.covs(smoothed=True)) < 1e-6
+
+
 # ---- dense output / saveat (src/solution.jl:165-210) -----------------------------------------------
 
 
