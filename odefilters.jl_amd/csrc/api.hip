@@ -559,7 +559,6 @@ int odef_solve_adaptive(odef_ctx* c, double t1, double abstol, double reltol, do
   if (!(dt0 > 0.0)) return fail(c, "odef_solve_adaptive: dt0 must be positive");
   if (max_steps < 1) return fail(c, "odef_solve_adaptive: max_steps must be >= 1");
   if (c->cfg.save_mode != ODEF_SAVE_EVERYSTEP) return fail(c, "odef_solve_adaptive: needs ODEF_SAVE_EVERYSTEP");
-  if (c->team_path) return fail(c, "odef_solve_adaptive: adaptive stepping is not built for the workgroup-per-trajectory path (rhs %d) yet", c->cfg.rhs_id);
   if ((size_t)c->TRI * (size_t)c->cfg.n_traj * sizeof(double) >= (1ull << 31))
     return fail(c, "odef_solve_adaptive: n_traj * D(D+1)/2 * 8 bytes must stay below 2 GiB per save slot; shard the ensemble");
   if (set_device(c)) return -1;
@@ -582,8 +581,9 @@ int odef_solve_adaptive(odef_ctx* c, double t1, double abstol, double reltol, do
   }
   HIPCHK(c, hipMemsetAsync(c->f[ODEF_F_T].ptr, 0, c->f[ODEF_F_T].valid, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  const int rc = c->jit ? jit_launch(c->jit->adaptive, (unsigned)((P.N + 63) / 64), 1, &P, c->stream)
-                        : launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 1, P, c->stream);
+  const int rc = c->jit         ? jit_launch(c->jit->adaptive, (unsigned)((P.N + 63) / 64), 1, &P, c->stream)
+                 : c->team_path ? launch_filter_pleiades_tiles(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 1)
+                                : launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 1, P, c->stream);
   if (rc) return fail(c, "odef_solve_adaptive: no kernel for rhs %d order %d", c->cfg.rhs_id, c->q);
   return finish_filter(c, 1);
 }

@@ -149,12 +149,26 @@ __global__ __launch_bounds__(kTilesBlock) void ek_filter_tiles_kernel(const Filt
   else
     TF::template run<false>(P, (long)blockIdx.x, (int)threadIdx.x, sm, &st);
 }
+template <class RHS, int q, bool EK1>
+__global__ __launch_bounds__(kTilesBlock) void ek_filter_tiles_adaptive_kernel(const FilterParams P) {
+  using TF = TilesFilter<RHS, q, EK1>;
+  __shared__ double sm[TF::W::size];
+  TileState st;
+  if (threadIdx.x >= kTilesThreads)
+    TF::template run_adaptive<true>(P, (long)blockIdx.x, (int)threadIdx.x, sm, &st);
+  else
+    TF::template run_adaptive<false>(P, (long)blockIdx.x, (int)threadIdx.x, sm, &st);
+}
 struct LaunchTilesFilter {
   const FilterParams& P;
   hipStream_t s;
+  int adaptive = 0;
   template <class RHS, int q, bool EK1>
   void operator()() {
-    hipLaunchKernelGGL((ek_filter_tiles_kernel<RHS, q, EK1>), dim3((unsigned)P.N), dim3(kTilesBlock), 0, s, P);
+    if (adaptive)
+      hipLaunchKernelGGL((ek_filter_tiles_adaptive_kernel<RHS, q, EK1>), dim3((unsigned)P.N), dim3(kTilesBlock), 0, s, P);
+    else
+      hipLaunchKernelGGL((ek_filter_tiles_kernel<RHS, q, EK1>), dim3((unsigned)P.N), dim3(kTilesBlock), 0, s, P);
   }
 };
 

@@ -34,7 +34,9 @@ struct TilesLds {
   static constexpr int G = A_size + B_size;  // d2 x d
   static constexpr int H0 = G + d2 * d;      // d x d
   static constexpr int MV = H0 + d * d, MT = MV + D, MP = MT + D, Z = MP + D, YV = Z + d, UP = YV + d, DU = UP + d;
-  static constexpr int BETA = DU + d, SC = BETA + d, COL = SC + 8, size = COL + D + d;  // col: D entries + d column sums
+  static constexpr int BETA = DU + d, SC = BETA + d, COL = SC + 8, COLEND = COL + D + d;  // col: D entries + d column sums
+  // adaptive stepping: this attempt's preconditioner table, diag(H Q H') for the error estimate, integ.u, control words
+  static constexpr int TAB = COLEND, WD = TAB + kTabStride, UC = WD + d, CTL = UC + d, size = CTL + 8;
   static_assert(d % kTile == 0, "tile size must divide the ODE dimension");
   static_assert(ntiles <= kTilesThreads && D <= kTilesThreads, "one thread per tile / per state row");
 };
@@ -191,6 +193,7 @@ struct TilesFilter {
         double acc = (r == s_) ? m1 * m1 : 0.0;
         for (int a = 0; a < d; ++a) acc += M0[r * d + a] * M0[s_ * d + a];
         WM[r * W::LDd + s_] = acc;
+        if (r == s_) sm[W::WD + r] = acc;  // diag(H Q H') for the error estimate (src/perform_step.jl:148-158)
       }
     )
     ODEF_STAMP(3)
@@ -449,15 +452,14 @@ _Pragma("unroll")
     ODEF_STAMP(11)
   }
 
-  // whole fixed-step solve of trajectory i.  `st`: one TileState (device) / kTilesThreads of them (host).
+  // tile ownership, congruence coefficients, zero covariance, Taylor-mode initial mean (src/state_initialization.jl)
   template <bool HELPER>
-  __device__ static inline void run(const FilterParams& P, long i, int tid_dev, double* __restrict__ sm, TileState* st) {
+  __device__ static inline void setup(const FilterParams& P, long i, const double* pl, int tid_dev, double* __restrict__ sm,
+                                      TileState* st) {
+    (void)tid_dev;
     double* m = sm + W::MV;
     double* sc = sm + W::SC;
     const size_t N = (size_t)P.N;
-    __attribute__((unused)) double pl_local[RHS::np > 0 ? RHS::np : 1];
-    const double* pl = pl_local;
-    for (int k = 0; k < RHS::np; ++k) pl_local[k] = P.p_shared ? P.p[k] : P.p[(size_t)k * N + i];
     ODEF_TILES_PHASE(
       S.I = -1;
       S.J = -1;
@@ -492,31 +494,51 @@ _Pragma("unroll")
         taylor_init<RHS, q>(u0, pl, m0);
         for (int k = 0; k < D; ++k) m[k] = m0[k];
         for (int k = 0; k < 8; ++k) sc[k] = 0.0;
+        for (int a = 0; a < d; ++a) sm[W::UC + a] = u0[a];
       }
     )
-    auto save = [&](long slot) {
-      ODEF_TILES_PHASE(
-        if (tid < D) P.mean[((size_t)slot * D + tid) * N + i] = m[tid];
-        if (S.I >= 0) {
+  }
+
+  // one saved record: mean, packed covariance (own tile), diffusion
+  template <bool HELPER>
+  __device__ static inline void save_record(const FilterParams& P, long i, long slot, double diffusion, int tid_dev,
+                                            double* __restrict__ sm, TileState* st) {
+    (void)tid_dev;
+    const double* m = sm + W::MV;
+    const size_t N = (size_t)P.N;
+    ODEF_TILES_PHASE(
+      if (tid < D) P.mean[((size_t)slot * D + tid) * N + i] = m[tid];
+      if (S.I >= 0) {
+        _Pragma("unroll")
+        for (int r = 0; r < TS; ++r)
           _Pragma("unroll")
-          for (int r = 0; r < TS; ++r)
-            _Pragma("unroll")
-            for (int c = 0; c < TS; ++c) {
-              const int a = S.I * TS + r;
-              const int b = S.J * TS + c;
-              if (b <= a) P.cov[((size_t)slot * TRI + tri(a, b)) * N + i] = S.x[r][c];
-            }
-        }
-        if (tid == 0) P.diff[(size_t)slot * N + i] = (slot == 0 && P.everystep) ? 0.0 : sc[4];
-      )
-    };
-    if (P.everystep) save(0);
+          for (int c = 0; c < TS; ++c) {
+            const int a = S.I * TS + r;
+            const int b = S.J * TS + c;
+            if (b <= a) P.cov[((size_t)slot * TRI + tri(a, b)) * N + i] = S.x[r][c];
+          }
+      }
+      if (tid == 0) P.diff[(size_t)slot * N + i] = diffusion;
+    )
+  }
+
+  // whole fixed-step solve of trajectory i.  `st`: one TileState (device) / kTilesThreads of them (host).
+  template <bool HELPER>
+  __device__ static inline void run(const FilterParams& P, long i, int tid_dev, double* __restrict__ sm, TileState* st) {
+    double* m = sm + W::MV;
+    double* sc = sm + W::SC;
+    const size_t N = (size_t)P.N;
+    __attribute__((unused)) double pl_local[RHS::np > 0 ? RHS::np : 1];
+    const double* pl = pl_local;
+    for (int k = 0; k < RHS::np; ++k) pl_local[k] = P.p_shared ? P.p[k] : P.p[(size_t)k * N + i];
+    setup<HELPER>(P, i, pl, tid_dev, sm, st);
+    if (P.everystep) save_record<HELPER>(P, i, 0, 0.0, tid_dev, sm, st);
     for (long n = 0; n < P.nsteps; ++n) {
       const double* tab = P.ptab + (size_t)P.tab_idx[n] * kTabStride;
       step<HELPER>(P.pc, pl, tab, P.fixed_diffusion != 0, (int)n, sm, st, tid_dev);
-      if (P.everystep) save(n + 1);
+      if (P.everystep) save_record<HELPER>(P, i, n + 1, sc[4], tid_dev, sm, st);
     }
-    if (!P.everystep) save(0);
+    if (!P.everystep) save_record<HELPER>(P, i, 0, sc[4], tid_dev, sm, st);
     ODEF_TILES_PHASE(
       if (tid == 0) {
         P.loglik[i] = sc[3];
@@ -528,6 +550,142 @@ _Pragma("unroll")
         bool ok = true;
         for (int k = 0; k < D; ++k) ok = ok && (fabs(m[k]) <= 1.79769313486231570815e+308);
         P.retcode[i] = ok ? 0 : 3;
+      }
+    )
+  }
+
+  // Adaptive solve of trajectory i: the lane kernel's loop (filter_adaptive_lane, ek_lane.h) with the scalar control
+  // -- step size, error estimate (src/perform_step.jl:78-84,148-158), PI controller, accept/commit -- done by tile
+  // thread 0, whose decisions reach everybody (the helper wavefront included) through LDS control words behind a
+  // barrier, so the loop stays workgroup-uniform.  One record per ATTEMPTED step, as in the lane kernel: a rejected
+  // attempt re-reads the previous record and writes it again at the unchanged time.
+  template <bool HELPER>
+  __device__ static inline void run_adaptive(const FilterParams& P, long i, int tid_dev, double* __restrict__ sm, TileState* st) {
+    double* m = sm + W::MV;
+    double* sc = sm + W::SC;
+    double* tabL = sm + W::TAB;
+    double* wd = sm + W::WD;
+    double* ucur = sm + W::UC;
+    double* ctl = sm + W::CTL;  // [0] go on, [1] restore the previous state, [2] slot of this attempt's record, [3] naccept,
+                                // [4] state finite
+    const size_t N = (size_t)P.N;
+    __attribute__((unused)) double pl_local[RHS::np > 0 ? RHS::np : 1];
+    const double* pl = pl_local;
+    for (int k = 0; k < RHS::np; ++k) pl_local[k] = P.p_shared ? P.p[k] : P.p[(size_t)k * N + i];
+    setup<HELPER>(P, i, pl, tid_dev, sm, st);
+    save_record<HELPER>(P, i, 0, 0.0, tid_dev, sm, st);
+    // controller state: meaningful in tile thread 0 only
+    const Controller& ct = P.ctrl;
+    double t = P.t0, h = P.dt0, qold = ct.qoldinit, q11 = 1.0, sc3_prev = 0.0, sc4_prev = 0.0;
+    int naccept = 0, nreject = 0, nsaved = 1, ret = 0;
+    long attempts = 0;
+    const long max_attempts = 20 * P.max_save + 1000;
+    ODEF_TILES_PHASE(
+      if (tid == 0) P.tsave[i] = P.t0;
+    )
+    for (;;) {
+      ODEF_TILES_PHASE(
+        if (tid == 0) {
+          double go = 1.0;
+          if (!(t < P.t1)) go = 0.0;
+          else if (nsaved >= P.max_save || attempts >= max_attempts) { ret = 1; go = 0.0; }  // MaxIters
+          else {
+            ++attempts;
+            h = fmin(h, ct.dtmax);
+            h = fmin(h, P.t1 - t);  // tstop clipping
+            if (!(h > ct.dtmin)) { ret = 2; go = 0.0; }  // DtLessThanMin
+            else {
+              precond_fill<NB>(h, precond_val<q>(h), tabL);
+              sc3_prev = sc[3];
+              sc4_prev = sc[4];
+            }
+          }
+          ctl[0] = go;
+          ctl[3] = (double)naccept;
+        }
+      )
+      if (ctl[0] == 0.0) break;  // workgroup-uniform
+      step<HELPER>(P.pc, pl, tabL, P.fixed_diffusion != 0, (int)ctl[3], sm, st, tid_dev);
+      ODEF_TILES_PHASE(
+        if (tid == 0) {
+          // DiffEqBase.calculate_residuals! + ODE_DEFAULT_NORM (src/perform_step.jl:78-84); sc[0] = local diffusion
+          double acc = 0.0;
+          for (int r = 0; r < d; ++r) {
+            const double es = sqrt(sc[0] * wd[r]);
+            const double e = h * es / (P.abstol + fmax(fabs(ucur[r]), fabs(m[r])) * P.reltol);
+            acc += e * e;
+          }
+          double EEst = sqrt(acc / d);
+          if (!(EEst == EEst) || !(fabs(EEst) <= 1.79769313486231570815e+308)) EEst = INFINITY;
+          for (int r = 0; r < d; ++r) ucur[r] = m[r];  // integ.u .= u_filt, also when rejected (src/perform_step.jl:86)
+          double qq;
+          if (EEst == 0.0) {
+            qq = 1.0 / ct.qmax;
+          } else {
+            q11 = pow(EEst, ct.beta1);
+            qq = q11 / pow(qold, ct.beta2);
+            qq = fmax(1.0 / ct.qmax, fmin(1.0 / ct.qmin, qq / ct.gamma));
+          }
+          const bool accepted = EEst <= 1.0;  // OrdinaryDiffEq accepts on <=, the cache commits on < (:89)
+          const bool restore = !(EEst < 1.0);
+          if (restore) {
+            sc[3] = sc3_prev;
+            sc[4] = sc4_prev;
+          }
+          if (accepted) {
+            if (qq <= ct.qsteady_max && qq >= ct.qsteady_min) qq = 1.0;
+            qold = fmax(EEst, ct.qoldinit);
+            double tn = t + h;
+            if (fabs(tn - P.t1) < 100.0 * 2.220446049250313e-16 * fmax(fabs(tn), fabs(P.t1))) tn = P.t1;
+            t = tn;
+            ++naccept;
+            h = h / qq;
+          } else {
+            ++nreject;
+            h = h / fmin(1.0 / ct.qmin, q11 / ct.gamma);
+          }
+          ctl[1] = restore ? 1.0 : 0.0;
+          ctl[2] = (double)nsaved;
+          P.tsave[(size_t)nsaved * N + i] = t;
+        }
+      )
+      const long slot = (long)ctl[2];
+      if (ctl[1] != 0.0) {  // x_filt is not committed: back to the previous record, cache.x = P^-1 (P x) (:73)
+        ODEF_TILES_PHASE(
+          if (tid < D) {
+            const double v = P.mean[((size_t)(slot - 1) * D + tid) * N + i];
+            m[tid] = tabL[kTabPIJ + tid / d] * (tabL[kTabPJ + tid / d] * v);
+          }
+          if (S.I >= 0) {
+            _Pragma("unroll")
+            for (int r = 0; r < TS; ++r)
+              _Pragma("unroll")
+              for (int c = 0; c < TS; ++c)
+                S.x[r][c] = P.cov[((size_t)(slot - 1) * TRI + symidx(S.I * TS + r, S.J * TS + c)) * N + i];
+          }
+        )
+      }
+      save_record<HELPER>(P, i, slot, sc[4], tid_dev, sm, st);
+      bool finite = true;
+      ODEF_TILES_PHASE(
+        if (tid == 0) {
+          ++nsaved;
+          for (int k = 0; k < D; ++k) finite = finite && (fabs(m[k]) <= 1.79769313486231570815e+308);
+          if (!finite) ret = 3;
+          ctl[4] = finite ? 1.0 : 0.0;  // its own word: ctl[0] is rewritten by thread 0 right after this barrier
+        }
+      )
+      if (ctl[4] == 0.0) break;
+    }
+    ODEF_TILES_PHASE(
+      if (tid == 0) {
+        P.loglik[i] = sc[3];
+        P.naccept[i] = naccept;
+        P.nreject[i] = nreject;
+        P.nf[i] = naccept + nreject;
+        P.njac[i] = IS_EK1 ? naccept + nreject : 0;
+        P.nsaved[i] = nsaved;
+        P.retcode[i] = ret;
       }
     )
   }

@@ -4,8 +4,8 @@ int launch_filter_pleiades(int q, int ek1, const TeamFilterParams& TP, hipStream
   LaunchTeamFilter f{TP, s};
   return dispatch_order<RhsPleiades>(q, ek1, f);
 }
-int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s) {
-  LaunchTilesFilter f{P, s};
+int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive) {
+  LaunchTilesFilter f{P, s, adaptive};
   return dispatch_order<RhsPleiades>(q, ek1, f);
 }
 int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s) {

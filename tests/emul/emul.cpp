@@ -230,18 +230,22 @@ extern "C" int emul_sample(const EmulSample* e, int d) {
 // register-tiled Pleiades filter (filter_tiles.h): all 320 tile threads emulated phase by phase, helper sections in line
 struct RunTilesFilter {
   const FilterParams& P;
+  int adaptive;
   template <class RHS, int q, bool EK1>
   void operator()() {
     using TF = TilesFilter<RHS, q, EK1>;
     std::vector<double> sm(TF::W::size);
     std::vector<TileState> st(kTilesThreads);
-    for (long i = 0; i < P.N; ++i) TF::template run<false>(P, i, 0, sm.data(), st.data());
+    for (long i = 0; i < P.N; ++i) {
+      if (adaptive) TF::template run_adaptive<false>(P, i, 0, sm.data(), st.data());
+      else TF::template run<false>(P, i, 0, sm.data(), st.data());
+    }
   }
 };
 extern "C" int emul_filter_tiles(const EmulArgs* a) {
   FilterParams P;
   fill(*a, P);
-  RunTilesFilter r{P};
+  RunTilesFilter r{P, a->adaptive};
   if (a->rhs != 5) return -2;
   return dispatch_order<RhsPleiades>(a->q, a->ek1, r);
 }

@@ -131,6 +131,27 @@ def test_pleiades_fixed_diffusion_tiles(ek1):
     np.testing.assert_allclose(r["diff"][0][-1], sol.diffusions[-1], rtol=1e-9)
 
 
+@pytest.mark.parametrize("q,ek1", [(2, True), (3, False)])
+def test_pleiades_adaptive_tiles(q, ek1):
+    """Adaptive stepping on the tiled workgroup path (TilesFilter::run_adaptive): same accept/reject sequence and
+    posterior as the oracle's OrdinaryDiffEq loop, then the team smoother over the per-attempt records."""
+    vf = orc.vector_field("pleiades")
+    alg = orc.Alg("EK1" if ek1 else "EK0", q, "dynamic", True)
+    kw = dict(abstol=1e-8, reltol=1e-6)
+    dt0 = 0.02  # far too large a first step: 4-5 rejected attempts before the controller settles
+    sol = orc.solve(vf, alg, adaptive=True, dt=dt0, tspan=(0.0, 0.05), **kw)
+    assert sol.nreject >= 3
+    r = E.emul_solve(vf.rhs_id, 28, q, ek1, vf.u0[None, :], vf.p, team="tiles", adaptive=True, t0=0.0, t1=0.05, dt0=dt0,
+                     max_save=256, smooth=True, **kw)
+    n = r["nsaved"][0]
+    assert r["retcode"][0] == 0 and n == len(sol.t) and r["nreject"][0] == sol.nreject, (n, len(sol.t), r["nreject"], sol.nreject)
+    assert r["nsaved_raw"][0] == n + sol.nreject  # one device record per attempted step
+    # step sizes come out of a (q+1)-th root of an error estimate that sits near rounding level relative to the state
+    np.testing.assert_allclose(r["tsave"][0][:n], sol.t, rtol=1e-6)
+    np.testing.assert_allclose(r["mean"][0][:n, :28], sol.means(smoothed=False)[:, :28], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(r["smean"][0][:n, :28], sol.means(smoothed=True)[:, :28], rtol=1e-7, atol=1e-12)
+
+
 @pytest.mark.parametrize("q", [4, 5])
 def test_rows_smoother_larger_state(q):
     """D = 15 / 18 (Lorenz, order 4 / 5): the row-per-lane team smoother (smooth_rows.h, 16- and 32-lane teams)."""

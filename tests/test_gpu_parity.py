@@ -289,11 +289,26 @@ def test_pleiades_ensemble_parity(pkg, q, kind):
                                        f"pleiades {kind}({q}) traj {i} smoothed={smoothed}")
 
 
-def test_pleiades_adaptive_is_rejected_loudly(pkg):
+@pytest.mark.parametrize("kind,q", [("EK1", 2), ("EK0", 3), ("EK1", 5)])
+def test_pleiades_adaptive(pkg, kind, q):
+    """The reference's default solve is adaptive: PI-controlled steps on the workgroup-per-trajectory path
+    (TilesFilter::run_adaptive), one device record per attempted step, team smoother over them.  The first step is far too
+    large, so the run starts with rejected attempts."""
     vf = orc.vector_field("pleiades")
-    prob = pkg.EnsembleProblem(pkg.ODEProblem("pleiades", vf.u0, (0.0, 0.01), ()), u0s=vf.u0[None, :])
-    with pytest.raises(pkg.OdefError, match="adaptive stepping is not built"):
-        pkg.solve(prob, pkg.EK1(order=3), pkg.EnsembleHIP(), adaptive=True, dt=1e-3)
+    N, t1, dt0 = 5, 0.05, 0.02
+    tol = dict(abstol=1e-8, reltol=1e-6)
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("pleiades", vf.u0, (0.0, t1), ()), perturb_scale=1e-3, n_perturbed=14)
+    sol = pkg.solve(ens, _alg(pkg, kind, q), pkg.EnsembleHIP(), trajectories=N, adaptive=True, dt=dt0, max_steps=256, **tol)
+    assert sol.retcode == ["Success"] * N
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-3, n_perturbed=14)
+    for i in (0, 4):
+        ref = orc.solve(vf, orc.Alg(kind, q, "dynamic", True), u0=u0s[i], adaptive=True, dt=dt0, tspan=(0.0, t1), **tol)
+        n = int(sol.nsaved[i])
+        assert (q == 5 or ref.nreject >= 1) and int(sol.destats.nreject[i]) == ref.nreject and n == len(ref.t)
+        np.testing.assert_allclose(sol.t[i, :n], ref.t, rtol=1e-6)
+        np.testing.assert_allclose(sol.x_filt_mean()[i, :n, :28], ref.means(smoothed=False)[:, :28], rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose(sol.u[i, :n], ref.u, rtol=1e-7, atol=1e-12)
+        assert sol.t[i, n - 1] == t1
 
 
 def test_pleiades_fixed_diffusion(pkg):
