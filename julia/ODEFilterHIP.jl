@@ -43,6 +43,23 @@ function fetch(ctx, field, ::Type{T}, dims...) where {T}
 end
 
 """
+    compile_rhs(name, source, d, n_params; include_dir) -> rhs_id
+
+Hand a user vector field to the library as HIP C++ source (`odef_rhs_compile`, include/odefilter.h): the stand-in for
+the closure `prob.f` (+ `f.jac`) that `perform_step!` calls at src/perform_step.jl:106,116-121.  The returned id goes
+into `OdefConfig.rhs_id` (register it in `RHS_IDS` under a symbol to use it with `EnsembleHIP(:name)`).
+"""
+function compile_rhs(name::AbstractString, source::AbstractString, d::Integer, n_params::Integer;
+                     include_dir::Union{Nothing,AbstractString}=nothing)
+    id = Ref{Int32}(-1)
+    rc = ccall((:odef_rhs_compile, LIB), Cint, (Cstring, Cstring, Int32, Int32, Cstring, Ptr{Int32}),
+               name, source, d, n_params, include_dir === nothing ? C_NULL : include_dir, id)
+    rc == 0 || error("libodefilter_hip: " * lasterr(C_NULL))   # the compiler log
+    RHS_IDS[Symbol(name)] = Int(id[])
+    return Int(id[])
+end
+
+"""
     __solve(ensembleprob, alg::Union{EK0,EK1}, ::EnsembleHIP; trajectories, dt, adaptive, abstol, reltol)
 
 `u0s` is a d x N matrix (column = trajectory) -- exactly the memory layout `odef_set_problem` expects.
