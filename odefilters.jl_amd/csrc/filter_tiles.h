@@ -1,10 +1,12 @@
-// Fixed-step EK0/EK1 filter for large state dimension (Pleiades: d = 28, D = 168), one workgroup
-// of 320 threads per trajectory with the packed covariance DISTRIBUTED IN REGISTERS: thread t owns
-// one 7 x 7 tile of the lower triangle (24 x 25 / 2 = 300 tiles at D = 168) for the whole solve; LDS
+// EK0/EK1 filter (fixed-step and adaptive) for large state dimension (Pleiades: d = 28, D = 168): one workgroup per
+// trajectory, 320 tile threads + one helper wavefront, with the packed covariance DISTRIBUTED IN REGISTERS: tile
+// thread t owns one 7 x 7 tile of the lower triangle (24 x 25 / 2 = 300 tiles at D = 168) for the whole solve; LDS
 // (<= 160 KB) is only the exchange medium.  Same arithmetic as EKStep::run (ek_math.h):
-//   congruence  A S A' + sigma2 Q     every thread gathers the <= 36 source tiles of its tile from LDS
-//   partial Cholesky (first 2d cols)  pivot column published to LDS, rank-1 update of the own tile
-//   Householder QR of (H L1)'         small, in LDS
+//   congruence  A S A'                every thread gathers the <= 36 source tiles of its tile from LDS
+//   chol(H Q H'), sigma2              helper wavefront, in registers, concurrent with the congruence (wave_vec.h)
+//   partial Cholesky (first 2d cols)  blocked: diagonal tile factored in registers, panel tiles solved, trailing
+//                                     tiles updated with two panel tiles read from LDS
+//   Householder QR of (H L1)', y      helper wavefront, row i of G in lane i, one shuffle butterfly per reflector
 //   rows of L1 times Q                one thread per row, row in registers, reflectors broadcast from LDS
 //   S_filt = Zp Zp' + Schur           own tile: 7 x 7 x d FMAs on 14 rows of Zp read from LDS; the Schur
 //                                     part never leaves the registers
