@@ -1,7 +1,8 @@
 // Wavefront-local vector type for the small sequential factorisations of the tiled filter.
 // The code that uses it is written once in "one value per lane" form:
 //   device  (gfx950): WD is a plain double in a VGPR, cross-lane traffic is v_readlane / ds_bpermute,
-//                     the section is executed by wavefront 0 only and needs no barrier at all;
+//                     the section is executed by ONE wavefront (the helper wavefront of filter_tiles.h) and
+//                     needs no barrier at all;
 //   host emulation  : WD is an array of 64 doubles with element-wise operators, so tests/emul runs the
 //                     very same algorithm (same operation order per lane) under g++.
 #pragma once

@@ -29,7 +29,10 @@ __global__ __launch_bounds__(128) void k_test(const double* Win, const double* z
     }
     const double acc = wv::chol_quadform<d>(wv::lds(WM), LD, wv::lds(z));
     if (threadIdx.x == 0) out_acc[0] = acc;
-    wv::householder_qr<d>(wv::lds(G), wv::lds(HV), wv::lds(beta), wv::lds(R));
+    __shared__ double yv[d];
+    double zSz, logacc;
+    wv::householder_qr_solve<d>(wv::lds(G), wv::lds(z), wv::lds(HV), wv::lds(beta), wv::lds(yv), zSz, logacc, wv::lds(R));
+    if (threadIdx.x == 0) { out_acc[1] = zSz; out_acc[2] = logacc; }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < d * d2; e += blockDim.x) outHV[e] = HV[e];
@@ -68,15 +71,16 @@ int main(int argc, char** argv) {
   std::vector<double> GtG(d * d, 0.0);
   for (int a = 0; a < d; ++a) for (int b = 0; b < d; ++b) for (int i = 0; i < d2; ++i) GtG[a * d + b] += G[i * d + a] * G[i * d + b];
   double *dW, *dz, *dG, *dacc, *dHV, *dbeta, *dR, *dms;
-  hipMalloc(&dW, W.size() * 8); hipMalloc(&dz, z.size() * 8); hipMalloc(&dG, G.size() * 8); hipMalloc(&dacc, 8);
+  hipMalloc(&dW, W.size() * 8); hipMalloc(&dz, z.size() * 8); hipMalloc(&dG, G.size() * 8); hipMalloc(&dacc, 24);
   hipMalloc(&dHV, d * d2 * 8); hipMalloc(&dbeta, d * 8); hipMalloc(&dR, d * d * 8); hipMalloc(&dms, 32 * 8);
   hipMemcpy(dW, W.data(), W.size() * 8, hipMemcpyHostToDevice);
   hipMemcpy(dz, z.data(), z.size() * 8, hipMemcpyHostToDevice);
   hipMemcpy(dG, G.data(), G.size() * 8, hipMemcpyHostToDevice);
   k_test<<<1, 128>>>(dW, dz, dG, dacc, dHV, dbeta, dR, dms);
-  double acc, ms[32];
+  double acc3[3], ms[32];
   std::vector<double> HV(d * d2), beta(d), R(d * d);
-  hipMemcpy(&acc, dacc, 8, hipMemcpyDeviceToHost);
+  hipMemcpy(acc3, dacc, 24, hipMemcpyDeviceToHost);
+  const double acc = acc3[0];
   hipMemcpy(ms, dms, 32 * 8, hipMemcpyDeviceToHost);
   hipMemcpy(HV.data(), dHV, HV.size() * 8, hipMemcpyDeviceToHost);
   hipMemcpy(beta.data(), dbeta, d * 8, hipMemcpyDeviceToHost);
@@ -109,6 +113,12 @@ int main(int argc, char** argv) {
   w2 /= gm;
   printf("max |Q'G - R| / max|G| = %.2e\n", w2);
   if (!(w2 < 1e-12)) ++bad;
+  {  // y = R^-T z: z'S^-1 z and log det from the host's R
+    double yh[d], zs = 0.0, la = 0.0;
+    for (int r = 0; r < d; ++r) { double s = z[r]; for (int c = 0; c < r; ++c) s -= R[c * d + r] * yh[c]; yh[r] = s / R[r * d + r]; zs += yh[r] * yh[r]; la += log(fabs(R[r * d + r])); }
+    printf("zSz dev %.15g ref %.15g, logdet dev %.15g ref %.15g\n", acc3[1], zs, acc3[2], la);
+    if (!(fabs(acc3[1] - zs) <= 1e-10 * fabs(zs)) || !(fabs(acc3[2] - la) <= 1e-10 * fabs(la) + 1e-12)) ++bad;
+  }
   printf(bad ? "FAIL\n" : "OK\n");
   return bad ? 1 : 0;
 }
