@@ -47,8 +47,8 @@ int main() {
   hipLaunchKernelGGL((ek_filter_tiles_kernel<RhsPleiades, q, true>), dim3((unsigned)N), dim3(kTilesBlock), 0, 0, P);
   CK(hipDeviceSynchronize());
   unsigned long long st[16]; CK(hipMemcpy(st, dst, sizeof st, hipMemcpyDeviceToHost));
-  const char* names[12] = {"(between steps / save)", "precondition + mean", "measure (f, J by one thread)", "z, H0, M0, W", "chol(W) + sigma2", "congruence A S A'",
-                           "partial Cholesky (56 cols)", "publish L1 + G", "Householder QR", "y, loglik", "rows of L1 x Q", "Gram + Schur"};
+  const char* names[12] = {"(between steps / save)", "precondition + mean", "measure (f, J by one thread)", "z, H0, M0, W", "chol(W) + sigma2 (helper, overlapped)", "congruence A S A'",
+                           "partial Cholesky (56 cols)", "publish L1 + G", "(unused)", "wait for the helper wavefront: QR, y, loglik", "rows of L1 x Q", "Gram + Schur"};
   double tot = 0; for (int k = 1; k < 12; ++k) tot += (double)st[k];
   printf("segment shares of one step (block 0, mean over %ld steps, stamps by thread 0)\n", nsteps);
   for (int k = 1; k < 12; ++k) printf("  %-32s %6.2f %%   %10.0f cycles/step/block\n", names[k], 100.0 * st[k] / tot, (double)st[k] / nsteps);
