@@ -95,6 +95,15 @@ __device__ unsigned long long g_stamp_last = 0;
 #define ODEF_TILES_HELPER(...) if constexpr (HELPER) { __VA_ARGS__ }
 #endif
 
+// step() has two callers per instantiation (the fixed-step and the adaptive kernel).  Left to the inliner it became an
+// out-of-line function: LDS pointers decayed to generic ones (FLAT instead of DS instructions), the tile registers
+// were spilled around the call, and the fixed-step kernel ran 1.5x slower.  Everything here is force-inlined.
+#ifdef ODEF_HOST_EMUL
+#define ODEF_TILES_FN static inline
+#else
+#define ODEF_TILES_FN __device__ __attribute__((always_inline)) static inline
+#endif
+
 template <class RHS, int q, bool IS_EK1>
 struct TilesFilter {
   static constexpr int d = RHS::d, NB = q + 1, D = d * NB, TRI = D * (D + 1) / 2, d2 = 2 * d;
@@ -102,7 +111,7 @@ struct TilesFilter {
   static constexpr int NT = kTilesThreads, TS = kTile, T2 = TS * TS, tpb = d / TS;  // tiles per derivative block
 
   template <bool HELPER>
-  __device__ static inline void step(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab,
+  ODEF_TILES_FN void step(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab,
                                      bool fixed_diffusion, int success_iter, double* __restrict__ sm, TileState* st,
                                      int tid_dev) {
     (void)tid_dev;
@@ -456,7 +465,7 @@ _Pragma("unroll")
 
   // tile ownership, congruence coefficients, zero covariance, Taylor-mode initial mean (src/state_initialization.jl)
   template <bool HELPER>
-  __device__ static inline void setup(const FilterParams& P, long i, const double* pl, int tid_dev, double* __restrict__ sm,
+  ODEF_TILES_FN void setup(const FilterParams& P, long i, const double* pl, int tid_dev, double* __restrict__ sm,
                                       TileState* st) {
     (void)tid_dev;
     double* m = sm + W::MV;
@@ -503,7 +512,7 @@ _Pragma("unroll")
 
   // one saved record: mean, packed covariance (own tile), diffusion
   template <bool HELPER>
-  __device__ static inline void save_record(const FilterParams& P, long i, long slot, double diffusion, int tid_dev,
+  ODEF_TILES_FN void save_record(const FilterParams& P, long i, long slot, double diffusion, int tid_dev,
                                             double* __restrict__ sm, TileState* st) {
     (void)tid_dev;
     const double* m = sm + W::MV;
@@ -526,7 +535,7 @@ _Pragma("unroll")
 
   // whole fixed-step solve of trajectory i.  `st`: one TileState (device) / kTilesThreads of them (host).
   template <bool HELPER>
-  __device__ static inline void run(const FilterParams& P, long i, int tid_dev, double* __restrict__ sm, TileState* st) {
+  ODEF_TILES_FN void run(const FilterParams& P, long i, int tid_dev, double* __restrict__ sm, TileState* st) {
     double* m = sm + W::MV;
     double* sc = sm + W::SC;
     const size_t N = (size_t)P.N;
@@ -562,7 +571,7 @@ _Pragma("unroll")
   // barrier, so the loop stays workgroup-uniform.  One record per ATTEMPTED step, as in the lane kernel: a rejected
   // attempt re-reads the previous record and writes it again at the unchanged time.
   template <bool HELPER>
-  __device__ static inline void run_adaptive(const FilterParams& P, long i, int tid_dev, double* __restrict__ sm, TileState* st) {
+  ODEF_TILES_FN void run_adaptive(const FilterParams& P, long i, int tid_dev, double* __restrict__ sm, TileState* st) {
     double* m = sm + W::MV;
     double* sc = sm + W::SC;
     double* tabL = sm + W::TAB;

@@ -99,6 +99,8 @@ inline WD shfl_xor(const WD& x, int m) {
   for (int l = 0; l < kLanes; ++l) r.v[l] = x.v[l ^ m];
   return r;
 }
+template <int M>
+inline WD shfl_xor_c(const WD& x) { return shfl_xor(x, M); }
 // lane l < n reads p[l * stride], the other lanes get 0
 inline WD load(const double* p, int stride, int n) {
   WD r;
@@ -148,6 +150,34 @@ __device__ inline WD shfl_xor(WD x, int m) {
   const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(x));
   return __hiloint2double(hi, lo);
 }
+// Value of lane (l xor M) for a compile-time M, without the LDS crossbar: gfx950's v_permlane32_swap /
+// v_permlane16_swap for M = 32 / 16 and DPP moves below that (row_ror:8, two bank-masked row shifts for 4,
+// quad_perm for 2 and 1) -- VALU latency instead of a ds_bpermute round trip in each of the six dependent stages of
+// the butterfly.  (Checked lane by lane against ds_bpermute: tools/lane_ops_test.hip.)
+template <int M>
+__device__ inline int shfl_xor_c32(int x) {
+  if constexpr (M == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (lane_id() & 32) ? (int)r[0] : (int)r[1];
+  } else if constexpr (M == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    return (lane_id() & 16) ? (int)r[0] : (int)r[1];
+  } else if constexpr (M == 8) {
+    return __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false);  // row_ror:8
+  } else if constexpr (M == 4) {
+    const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);  // row_shl:4 into banks 0, 2
+    return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);          // row_shr:4 into banks 1, 3
+  } else if constexpr (M == 2) {
+    return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+  } else {
+    static_assert(M == 1, "xor mask must be a power of two below 64");
+    return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+  }
+}
+template <int M>
+__device__ inline WD shfl_xor_c(WD x) {
+  return __hiloint2double(shfl_xor_c32<M>(__double2hiint(x)), shfl_xor_c32<M>(__double2loint(x)));
+}
 __device__ inline WD load(LdsCP p, int stride, int n) { return lane_id() < n ? p[lane_id() * stride] : 0.0; }
 __device__ inline void store(LdsP p, int stride, WB mask, WD x) {
   if (mask) p[lane_id() * stride] = x;
@@ -188,10 +218,10 @@ struct MultiSum {
         for (int j = 0; j < half; ++j) {
           const WD send = select(up, p[j], p[j + half]);
           const WD keep = select(up, p[j + half], p[j]);
-          p[j] = keep + shfl_xor(send, m);
+          p[j] = keep + shfl_xor_c<m>(send);
         }
       } else {
-        p[0] = p[0] + shfl_xor(p[0], m);
+        p[0] = p[0] + shfl_xor_c<m>(p[0]);
       }
     });
   }
