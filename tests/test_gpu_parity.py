@@ -626,6 +626,28 @@ def test_stiff_vanderpol(pkg):
     np.testing.assert_allclose(sol.u[0, n - 1], ref.u[-1], rtol=1e-3)
 
 
+def test_non_uniform_fixed_grid(pkg):
+    """`tstops` as the full grid with several distinct step sizes (one preconditioner table per distinct h, built on the
+    host with the reference's running product, src/preconditioning.jl:9-14), filter + smoother + dense output."""
+    vf = orc.vector_field("lorenz63")
+    hs = np.array([2.0**-9, 2.0**-8, 3 * 2.0**-10, 2.0**-9, 2.0**-7, 2.0**-8, 5 * 2.0**-11] * 6)
+    grid = np.concatenate([[0.0], np.cumsum(hs)])
+    N = 66
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, (0.0, float(grid[-1])), vf.p), perturb_scale=1e-2)
+    sol = pkg.solve(ens, pkg.EK1(order=3), pkg.EnsembleHIP(), trajectories=N, adaptive=False, tstops=grid)
+    np.testing.assert_array_equal(sol.t, grid)
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    consts = orc.make_consts(3, 3)
+    for i in (0, 65):
+        ref = orc.solve(vf, orc.EK1(order=3), u0=u0s[i], tspan=(0.0, float(grid[-1])), tgrid=grid)
+        np.testing.assert_allclose(sol.x_filt_mean()[i][:, :3], ref.means(smoothed=False)[:, :3], rtol=1e-10)
+        np.testing.assert_allclose(sol.u[i], ref.u, rtol=1e-9)
+        assert P.cov_err(sol.x_smooth_cov()[i], ref.covs(smoothed=True)) < 1e-5
+        tq = np.array([0.5 * (grid[3] + grid[4]), 0.9 * grid[-1]])
+        want = np.array([orc.dense_output(ref, consts, float(t)).mu[:3] for t in tq])
+        np.testing.assert_allclose(sol(tq)[0][i][:, :3], want, rtol=1e-8)
+
+
 # ---- edge cases ------------------------------------------------------------------------------------------
 
 
