@@ -278,8 +278,9 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
     if (EEst == 0.0) {
       qq = 1.0 / ct.qmax;
     } else {
-      q11 = pow(EEst, ct.beta1);
-      qq = q11 / pow(qold, ct.beta2);
+      // x^b = exp(b log x) for the positive arguments of the controller: 1e-15 relative, a third of pow()'s instructions
+      q11 = exp(ct.beta1 * log(EEst));
+      qq = q11 * exp(-ct.beta2 * log(qold));
       qq = fmax(1.0 / ct.qmax, fmin(1.0 / ct.qmin, qq / ct.gamma));
     }
     const bool accepted = EEst <= 1.0;  // OrdinaryDiffEq accepts on <=
