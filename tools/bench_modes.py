@@ -23,7 +23,10 @@ for mode in args.modes.split(","):
         f_ms, s_ms = ctx.kernel_time_ms(0)[0], ctx.kernel_time_ms(1)[0]
         nb = (2 * 8 * (D + TRI + 1) - 8) * N * (ns - 1)
         print(json.dumps({"mode": "smooth", "traj": N, "nsteps": ns, "filter_ms": f_ms, "smooth_ms": s_ms,
-                          "smoother_steps_per_s": N * (ns - 1) / (s_ms * 1e-3), "alg_GBps": nb / (s_ms * 1e-3) / 1e9}))
+                          "smoother_steps_per_s": N * (ns - 1) / (s_ms * 1e-3), "alg_GBps": nb / (s_ms * 1e-3) / 1e9,
+                          "roofline": {"bound": "hbm", "achieved": nb / (s_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                       "frac": nb / (s_ms * 1e-3) / 1e9 / 8000.0,
+                                       "note": "algorithmic bytes = read the filter record + write the smoothed one (2 B_alg - 8 per step)"}}))
         ctx.close()
     elif mode == "adaptive":
         ctx = pkg.Context("lorenz63", 3, 1, N, smooth=True)
@@ -48,7 +51,10 @@ if "pleiades" in args.modes.split(","):
     D = 168
     F_alg = (16 / 3) * D**3 + 8 * 28 * D**2 + 4 * D**2
     print(json.dumps({"mode": "pleiades", "traj": N, "nsteps": nsp, "filter_ms": f_ms, "steps_per_s": N * nsp / (f_ms * 1e-3),
-                      "F_alg_TFLOPs": F_alg * N * nsp / (f_ms * 1e-3) / 1e12, "retcodes_ok": bool((ctx.get(10) == 0).all())}))
+                      "F_alg_TFLOPs": F_alg * N * nsp / (f_ms * 1e-3) / 1e12, "retcodes_ok": bool((ctx.get(10) == 0).all()),
+                      "roofline": {"bound": "fp64-vector (v_mfma_f64 issues at the same rate on MI355X)", "achieved": F_alg * N * nsp / (f_ms * 1e-3) / 1e12,
+                                   "peak": 78.6, "unit": "TFLOP/s", "frac": F_alg * N * nsp / (f_ms * 1e-3) / 1e12 / 78.6,
+                                   "note": "dense-algebra count F_alg of SURVEY 8(d); the structure-exploiting kernel executes fewer real flops"}}))
     ctx.close()
 if "pleiades_smooth" in args.modes.split(","):
     u0 = [3.0, 3.0, -1.0, -3.0, 2.0, -2.0, 2.0, 3.0, -3.0, 2.0, 0.0, 0.0, -4.0, 4.0,
