@@ -1,6 +1,7 @@
 """Parity of the HIP kernels (through the C ABI, libodefilter_hip.so) with the oracle and the
 committed golden fixtures.  Needs a real MI355X: run with `-m gpu`."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -646,6 +647,18 @@ def test_non_uniform_fixed_grid(pkg):
         tq = np.array([0.5 * (grid[3] + grid[4]), 0.9 * grid[-1]])
         want = np.array([orc.dense_output(ref, consts, float(t)).mu[:3] for t in tq])
         np.testing.assert_allclose(sol(tq)[0][i][:, :3], want, rtol=1e-8)
+
+
+def test_random_configuration_sweep(pkg, monkeypatch):
+    """tools/parity_sweep.py: 60 random (vector field, order, EK0/EK1, diffusion model, fixed/adaptive, u0, p, dt)
+    configurations against the oracle; a configuration may only be waived when the oracle's own 1-ulp spread explains
+    the difference, and a diverging one must be reported Unstable where the oracle raises."""
+    import runpy
+
+    monkeypatch.setattr(sys, "argv", ["parity_sweep.py", "5", "60"])
+    with pytest.raises(SystemExit) as ex:
+        runpy.run_path(os.path.join(os.path.dirname(GOLD), "..", "tools", "parity_sweep.py"), run_name="__main__")
+    assert ex.value.code == 0
 
 
 # ---- edge cases ------------------------------------------------------------------------------------------
