@@ -18,7 +18,7 @@ namespace odef {
 
 constexpr int kWave = 64;
 
-template <class RHS, int q, bool EK1, bool EVERY>
+template <class RHS, int q, bool EK1, bool EVERY, bool LAG = false>
 __global__ __launch_bounds__(kWave) void ek_filter_fixed_kernel(const FilterParams P) {
   const long i0 = (long)blockIdx.x * kWave;  // wave-uniform
   // All waves run the same instruction stream and would reach their per-step store burst
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(kWave) void ek_filter_fixed_kernel(const FilterPara
     const int n = (int)(blockIdx.x % 16u) * P.stagger;
     for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
   }
-  if (i0 + threadIdx.x < P.N) filter_fixed_lane<RHS, q, EK1, EVERY>(P, i0, threadIdx.x);
+  if (i0 + threadIdx.x < P.N) filter_fixed_lane<RHS, q, EK1, EVERY, LAG>(P, i0, threadIdx.x);
 }
 template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kWave) void ek_filter_adaptive_kernel(const FilterParams P) {
@@ -55,6 +55,13 @@ constexpr int kSmoothLaneMaxD = 12;
 // Ensemble size from which the lane kernel is used.  Measured on Lorenz EK1(3), 1 023 steps: N = 2 048 / 4 096:
 // 27.6 / 27.7 ms (lane) against 13.9 / 15.5 ms (row teams); N = 16 384: 30.4 against 42.4 ms.
 // ODEF_SMOOTH_LANE_MIN_N overrides it (read at every launch, so tests can exercise both kernels).
+// Ensemble size below which the every-step filter stores its records lagged by one step (LaggedSink, ek_lane.h);
+// ODEF_FILTER_LAG_MAX_N overrides it (read at every launch).
+constexpr long kFilterLagMaxN = 32768;
+inline long filter_lag_max_n() {
+  const char* e = getenv("ODEF_FILTER_LAG_MAX_N");
+  return e ? atol(e) : kFilterLagMaxN;
+}
 constexpr long kSmoothLaneMinN = 6144;
 inline long smooth_lane_min_n() {
   const char* e = getenv("ODEF_SMOOTH_LANE_MIN_N");
@@ -198,6 +205,8 @@ struct LaunchFilter {
   void operator()() {
     const unsigned grid = (unsigned)((P.N + kWave - 1) / kWave);
     if (adaptive) hipLaunchKernelGGL((ek_filter_adaptive_kernel<RHS, q, EK1>), dim3(grid), dim3(kWave), 0, s, P);
+    else if (P.everystep && P.N < filter_lag_max_n())  // small ensemble: spread the record stores over the next step
+      hipLaunchKernelGGL((ek_filter_fixed_kernel<RHS, q, EK1, true, true>), dim3(grid), dim3(kWave), 0, s, P);
     else if (P.everystep) hipLaunchKernelGGL((ek_filter_fixed_kernel<RHS, q, EK1, true>), dim3(grid), dim3(kWave), 0, s, P);
     else hipLaunchKernelGGL((ek_filter_fixed_kernel<RHS, q, EK1, false>), dim3(grid), dim3(kWave), 0, s, P);
   }

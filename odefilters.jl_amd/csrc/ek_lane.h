@@ -100,6 +100,37 @@ struct RecordSink {
   RowStore sm, sc;
   __device__ inline void mean(double v) { sm.put(v); }
   __device__ inline void cov(double v) { sc.put(v); }
+  __device__ inline void tick() {}
+};
+
+// Sink that stores the record of the PREVIOUS step -- the inputs (m, C) of the running step, which stay in registers
+// until their own store has been issued -- one value per tick(), i.e. spread evenly over the arithmetic of the step.
+// A wavefront can have 63 vector-memory operations in flight and a record is 91 stores at D = 12, so a burst at the
+// end of a step parks the wave until 28 of them have completed.  For a LARGE ensemble that wait is hidden behind the
+// HBM-bound stream anyway (same time either way, and the lagged form costs 10 % more VALU instructions in AGPR
+// moves); for a SMALL ensemble (one wave on a few SIMDs, memory system idle) it is exposed latency: at 4 096
+// trajectories 6.2 ms with the burst, 5.8 ms lagged (4.5 ms without stores at all; the rest is the instructions of
+// the stores themselves).  `next` is a compile-time constant at every call site once run() is unrolled.
+template <int D, int TRI>
+struct LaggedSink {
+  const double (&m)[D];
+  const double (&C)[TRI];
+  double diffusion;
+  RowStore sm, sc, sd;
+  int next;
+  __device__ inline void mean(double) {}
+  __device__ inline void cov(double) {}
+  __device__ inline void tick() {
+    if (next < D) sm.put(m[next]);
+    else if (next < D + TRI) sc.put(C[next - D]);
+    else if (next == D + TRI) sd.put(diffusion);
+    ++next;
+  }
+  __device__ inline void flush() {
+#pragma unroll
+    for (int k = 0; k <= D + TRI; ++k)
+      if (k >= next) tick();
+  }
 };
 
 template <int D>
@@ -112,7 +143,8 @@ __device__ inline bool all_finite(const double (&m)[D]) {
 
 // EVERY: every step is saved (compile-time: with a run-time flag each of the 91 stores of a step sat behind
 // its own branch, which cost 10 % in instructions and scheduling).
-template <class RHS, int q, bool IS_EK1, bool EVERY>
+// LAG (with EVERY): the record of step n is stored while step n + 1 runs (LaggedSink) -- for small ensembles.
+template <class RHS, int q, bool IS_EK1, bool EVERY, bool LAG = false>
 __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigned lane) {
   const long i = i0 + lane;
   using S = EKStep<RHS, q, IS_EK1>;
@@ -128,7 +160,7 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigne
   taylor_init<RHS, q>(u0, pl, m);
 #pragma unroll
   for (int k = 0; k < TRI; ++k) C[k] = 0.0;
-  if constexpr (EVERY) store_state<D, TRI>(P, 0, i0, lane, m, C, 0.0);
+  if constexpr (EVERY && !LAG) store_state<D, TRI>(P, 0, i0, lane, m, C, 0.0);
 
   double loglik = 0.0, gdiff = 0.0;
   int chol_fix = 0;
@@ -138,7 +170,14 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigne
     StepAux aux;
     aux.chol_fix = 0;
     const size_t Nn = (size_t)P.N;
-    if constexpr (EVERY) {
+    if constexpr (EVERY && LAG) {  // record n = the inputs of this step
+      LaggedSink<D, TRI> sink{m, C, gdiff,
+                              RowStore(P.mean + ((size_t)n * D * Nn + i0), Nn, D, lane),
+                              RowStore(P.cov + ((size_t)n * TRI * Nn + i0), Nn, TRI, lane),
+                              RowStore(P.diff + ((size_t)n * Nn + i0), Nn, 1, lane), 0};
+      S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux, sink);
+      sink.flush();
+    } else if constexpr (EVERY) {
       RecordSink sink{RowStore(P.mean + ((size_t)(n + 1) * D * Nn + i0), Nn, D, lane),
                       RowStore(P.cov + ((size_t)(n + 1) * TRI * Nn + i0), Nn, TRI, lane)};
       S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux, sink);
@@ -153,12 +192,13 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigne
     loglik += aux.loglik;
     gdiff = aux.sigma2_global;
     chol_fix += aux.chol_fix;
-    if constexpr (EVERY) {
+    if constexpr (EVERY && !LAG) {
       RowStore sd(P.diff + ((size_t)(n + 1) * Nn + i0), Nn, 1, lane);
       sd.put(gdiff);
     }
   }
   if constexpr (!EVERY) store_state<D, TRI>(P, 0, i0, lane, m, C, gdiff);
+  if constexpr (EVERY && LAG) store_state<D, TRI>(P, P.nsteps, i0, lane, m, C, gdiff);  // the last record
   P.loglik[i] = loglik;
   P.naccept[i] = (int)P.nsteps;
   P.nreject[i] = 0;

@@ -171,8 +171,14 @@ __host__ __device__ inline void precond_fill(double h, double pval, double* tab)
 // triangular: the Gram matrix of `_L = [A*L  sqrt(sigma2)*Q_L]` (src/filtering.jl:34-35).
 // A = E_{NB-2} ... E_1 E_0 with E_J = I + sum_{j>J} At[J][j] e_J e_j' (block row J picks up the
 // still-untouched block rows j > J), applied as successive symmetric congruences.
-template <int d, int NB>
-__device__ inline void predict_cov_inplace(const PriorConsts& pc, double (&X)[d * NB * (d * NB + 1) / 2], double sigma2) {
+struct NoTick {
+  __device__ inline void operator()() const {}
+};
+// `tick()` is called at regular points of the arithmetic; the lagged record sink of the filter (ek_lane.h) uses it to
+// spread the stores of the previous record over the step.
+template <int d, int NB, class Tick = NoTick>
+__device__ inline void predict_cov_inplace(const PriorConsts& pc, double (&X)[d * NB * (d * NB + 1) / 2], double sigma2,
+                                           Tick tick = Tick{}) {
   constexpr int D = d * NB;
 #pragma unroll
   for (int J = 0; J + 1 < NB; ++J) {
@@ -187,9 +193,11 @@ __device__ inline void predict_cov_inplace(const PriorConsts& pc, double (&X)[d 
         for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * X[symidx(j * d + a, J * d + b)];
         Wd[a][b] = t;
       }
+    tick();
     // off-diagonal blocks of block row J: X_Jk += sum_j a_j X_jk  (k != J)
 #pragma unroll
-    for (int a = 0; a < d; ++a)
+    for (int a = 0; a < d; ++a) {
+      tick();
 #pragma unroll
       for (int c = 0; c < D; ++c) {
         if (c / d == J) continue;
@@ -198,6 +206,7 @@ __device__ inline void predict_cov_inplace(const PriorConsts& pc, double (&X)[d 
         for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * X[symidx(j * d + a, c)];
         X[symidx(J * d + a, c)] = t;
       }
+    }
     // Y_JJ = W_JJ + sum_j a_j W_Jj
 #pragma unroll
     for (int a = 0; a < d; ++a)
@@ -260,8 +269,8 @@ struct EKStep {
   //   K = (L1 Q)[:, :d] R^-T,   Sigma_filt = (L1 Q)[:, d:2d] (L1 Q)[:, d:2d]' + Schur complement,
   // which is the Gram matrix of (I - K H) L without ever forming K H.
   // `sink.mean(v)` / `sink.cov(v)` receive the un-preconditioned results in storage order as soon as each
-  // value exists, so that a caller that saves every step can issue its stores inside the final loops
-  // instead of in one burst after the step.
+  // value exists; `sink.tick()` is called at ~110 points spread evenly over the arithmetic of the step (never
+  // inside a run-time branch), so that a sink can spread its stores over the step (LaggedSink, ek_lane.h).
   template <class Sink>
   __device__ static inline void run(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab,
                                     bool fixed_diffusion, bool want_loglik, int success_iter, double prev_global,
@@ -273,9 +282,11 @@ struct EKStep {
     for (int i = 0; i < D; ++i) mt[i] = tab[kTabPJ + i / d] * m[i];
     double X[TRI];
 #pragma unroll
-    for (int i = 0; i < D; ++i)
+    for (int i = 0; i < D; ++i) {
+      if (i % 2 == 1) sink.tick();
 #pragma unroll
       for (int j = 0; j <= i; ++j) X[tri(i, j)] = C[tri(i, j)] * tab[kTabPP + (i / d) * MAXNB + (j / d)];
+    }
 
     // predict mean (src/filtering.jl:22-25)
     double mp[D];
@@ -294,9 +305,11 @@ struct EKStep {
     double up[d], du[d], z[d];
 #pragma unroll
     for (int a = 0; a < d; ++a) up[a] = pi0 * mp[a];
+    sink.tick();
     RHS::f(up, p, du);
 #pragma unroll
     for (int a = 0; a < d; ++a) z[a] = pi1 * mp[d + a] - du[a];
+    sink.tick();
     // H = (E1 - J E0) PI  -> blocks H0 = -J*pi0, H1 = I*pi1 ; EK0: H0 = 0
     double H0[d][d];
     if constexpr (IS_EK1) {
@@ -313,6 +326,7 @@ struct EKStep {
         for (int a = 0; a < d; ++a) H0[r][a] = 0.0;
     }
     const double h1 = pi1;  // H1 = h1 * I
+    sink.tick();
 
     // M = H Q_L (d x 2d nonzero), W = M M' = H Q H'   (src/diffusions.jl:78)
     double W[d][d];
@@ -339,6 +353,7 @@ struct EKStep {
         }
     }
 
+    sink.tick();
     double sigma2_pred = 1.0;  // diffusion used inside predict_cov!
     if (!fixed_diffusion) {
       // DynamicDiffusion (src/diffusions.jl:72-80): sigma^2 = z' (H Q H')^-1 z / d = |Lw^-1 z|^2 / d
@@ -360,9 +375,11 @@ struct EKStep {
 
     // predict_cov! (src/filtering.jl:33-41): Gram matrix, then Cholesky -- first 2d columns,
     // right-looking, so that X[i>=2d][j>=2d] ends as the Schur complement L2 L2'.
-    predict_cov_inplace<d, NB>(pc, X, sigma2_pred);
+    sink.tick();
+    predict_cov_inplace<d, NB>(pc, X, sigma2_pred, [&]() { sink.tick(); });
 #pragma unroll
     for (int k = 0; k < d2; ++k) {
+      sink.tick();
       const double piv = X[tri(k, k)];
       const bool ok = piv > 0.0;  // a failing pivot is the reference's QR-fallback case (src/filtering.jl:38-47)
       const double lkk = ok ? sqrt(piv) : 0.0;
@@ -373,6 +390,7 @@ struct EKStep {
       for (int i = k + 1; i < D; ++i) X[tri(i, k)] *= inv;
 #pragma unroll
       for (int j = k + 1; j < D; ++j) {
+        if ((j - k) % 4 == 0) sink.tick();
         const double ljk = X[tri(j, k)];
 #pragma unroll
         for (int i = j; i < D; ++i) X[tri(i, j)] -= X[tri(i, k)] * ljk;
@@ -382,7 +400,8 @@ struct EKStep {
     // G = (H L1)' (2d x d):  G[c][r] = sum_{k>=c} H[r][k] L[k][c]
     double G[d2][d];
 #pragma unroll
-    for (int c = 0; c < d2; ++c)
+    for (int c = 0; c < d2; ++c) {
+      if (c % 2 == 0) sink.tick();
 #pragma unroll
       for (int r = 0; r < d; ++r) {
         double s = 0.0;
@@ -393,10 +412,12 @@ struct EKStep {
         if (d + r >= c) s += h1 * X[tri(d + r, c)];
         G[c][r] = s;
       }
+    }
     // Householder QR of G: G = Q [R; 0];  S = G'G = R'R  (measurement covariance, src/perform_step.jl:54)
     double hv[d][d2], hbeta[d], R[d][d];
 #pragma unroll
     for (int k = 0; k < d; ++k) {
+      sink.tick();
       double nrm2 = 0.0;
 #pragma unroll
       for (int i = k; i < d2; ++i) nrm2 += G[i][k] * G[i][k];
@@ -411,6 +432,7 @@ struct EKStep {
 #pragma unroll
       for (int i = k + 1; i < d2; ++i) hv[k][i] = G[i][k];
       R[k][k] = alpha;
+      sink.tick();
 #pragma unroll
       for (int c = k + 1; c < d; ++c) {
         double s = v0 * G[k][c];
@@ -427,6 +449,7 @@ struct EKStep {
     double y[d], zSz = 0.0, detprod = 1.0, logacc = 0.0;
 #pragma unroll
     for (int r = 0; r < d; ++r) {
+      sink.tick();
       double t = z[r];
 #pragma unroll
       for (int c = 0; c < r; ++c) t -= R[c][r] * y[c];
@@ -451,18 +474,22 @@ struct EKStep {
     }
 
     // error estimate scale (src/perform_step.jl:148-158)
+    sink.tick();
 #pragma unroll
     for (int r = 0; r < d; ++r) err_scale[r] = sqrt(aux.sigma2_local * W[r][r]);
+    sink.tick();
 
     // update! (src/filtering.jl:79-91): rows of L1 times Q
     double Zp[D][d];
 #pragma unroll
     for (int l = 0; l < D; ++l) {
+      sink.tick();
       double w[d2];
 #pragma unroll
       for (int c = 0; c < d2; ++c) w[c] = (c <= l) ? X[tri(l, c)] : 0.0;
 #pragma unroll
       for (int k = 0; k < d; ++k) {
+        if (k % 2 == 1) sink.tick();
         double s = 0.0;
 #pragma unroll
         for (int c = k; c < d2; ++c) s += w[c] * hv[k][c];
@@ -476,6 +503,7 @@ struct EKStep {
       for (int r = 0; r < d; ++r) t -= w[r] * y[r];
       m_out[l] = tab[kTabPIJ + l / d] * t;  // un-precondition (src/perform_step.jl:75)
       sink.mean(m_out[l]);
+      sink.tick();
 #pragma unroll
       for (int r = 0; r < d; ++r) Zp[l][r] = w[d + r];
     }
@@ -484,6 +512,7 @@ struct EKStep {
     for (int i = 0; i < D; ++i)
 #pragma unroll
       for (int j = 0; j <= i; ++j) {
+        if (tri(i, j) % 4 == 0) sink.tick();
         double s = (j >= d2) ? X[tri(i, j)] : 0.0;
 #pragma unroll
         for (int r = 0; r < d; ++r) s += Zp[i][r] * Zp[j][r];
@@ -496,6 +525,7 @@ struct EKStep {
 struct NoSink {
   __device__ inline void mean(double) {}
   __device__ inline void cov(double) {}
+  __device__ inline void tick() {}
 };
 
 // Taylor-mode initialisation (src/state_initialization.jl:2-53): m0 = [u0; u'(t0); ...; u^(q)(t0)],

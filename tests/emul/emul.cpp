@@ -45,7 +45,8 @@ static void fill(const EmulArgs& a, FilterParams& P) {
   P.t0 = a.t0; P.t1 = a.t1; P.abstol = a.abstol; P.reltol = a.reltol; P.dt0 = a.dt0;
   std::memcpy(&P.ctrl, a.ctrl, sizeof(Controller));
   P.max_save = a.max_save;
-  P.everystep = a.everystep; P.fixed_diffusion = a.fixed_diffusion; P.want_loglik = a.want_loglik;
+  P.everystep = a.everystep != 0; P.fixed_diffusion = a.fixed_diffusion; P.want_loglik = a.want_loglik;
+  P.stagger = a.everystep == 2 ? 7 : 0;  // everystep == 2: the lagged record stores of the small-ensemble kernel
   P.mean = a.mean; P.cov = a.cov; P.diff = a.diff; P.tsave = a.tsave; P.loglik = a.loglik;
   P.naccept = a.naccept; P.nreject = a.nreject; P.nf = a.nf; P.njac = a.njac; P.nsaved = a.nsaved;
   P.retcode = a.retcode;
@@ -59,6 +60,7 @@ struct RunFilter {
     for (long i = 0; i < P.N; ++i) {
       const long i0 = (i / 64) * 64;
       if (adaptive) filter_adaptive_lane<RHS, q, EK1>(P, i0, (unsigned)(i - i0));
+      else if (P.everystep && P.stagger == 7) filter_fixed_lane<RHS, q, EK1, true, true>(P, i0, (unsigned)(i - i0));  // lagged record stores
       else if (P.everystep) filter_fixed_lane<RHS, q, EK1, true>(P, i0, (unsigned)(i - i0));
       else filter_fixed_lane<RHS, q, EK1, false>(P, i0, (unsigned)(i - i0));
     }

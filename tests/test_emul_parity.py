@@ -63,6 +63,17 @@ def test_adaptive_matches_oracle_step_sequence():
     np.testing.assert_allclose(r["smean"][0][:n, :3], sol.means(smoothed=True)[:, :3], rtol=1e-7)
 
 
+def test_lagged_record_stores_give_the_same_records():
+    """The small-ensemble variant of the every-step filter stores record n while step n + 1 runs (LaggedSink): same bits."""
+    vf = orc.vector_field("lorenz63")
+    u0s = orc.ensemble_u0(vf.u0, 3, 1e-2)
+    tg = np.arange(41) * 2.0**-8
+    a = E.emul_solve(vf.rhs_id, 3, 3, True, u0s, vf.p, tgrid=tg, everystep=1)
+    b = E.emul_solve(vf.rhs_id, 3, 3, True, u0s, vf.p, tgrid=tg, everystep=2)
+    for key in ("mean", "cov", "diff", "loglik"):
+        np.testing.assert_array_equal(a[key], b[key])
+
+
 def test_ensemble_lanes_are_independent():
     """Lane i of a batch equals the single-trajectory run of u0_i (bitwise)."""
     vf = orc.vector_field("lorenz63")
