@@ -147,10 +147,12 @@ const char* odef_last_error(const odef_ctx* ctx); /* ctx may be NULL: last error
  *           // without it EK1 differentiates f in forward mode (the reference's ForwardDiff fallback, :119-121)
  *     };
  *
- * hiprtc compiles the library's own lane kernels around it for gfx950 (include_dir = directory holding the csrc
- * headers; NULL: $ODEFILTER_HIP_INCLUDE or the build-time location).  Returns 0 and a new rhs id (>= 100) for
+ * A hipcc child process ($ODEFILTER_HIP_HIPCC, else hipcc on PATH, else /opt/rocm/bin/hipcc) compiles the library's
+ * own lane kernels around it for gfx950 (include_dir = directory holding the csrc headers; NULL: $ODEFILTER_HIP_INCLUDE
+ * or the build-time location).  Returns 0 and a new rhs id (>= 100) for
  * odef_config.rhs_id; on a compile error returns -1 and odef_last_error(NULL) holds the compiler log.
- * Filter: d(q+1) <= 15; smoother, dense output and sampling: d(q+1) <= 12. */
+ * Filter and smoother: d(q+1) <= 20 as far as the kernels fit the register file (a dimension that does not is rejected
+ * here, with the log); dense output and sampling: d(q+1) <= 12. */
 int odef_rhs_compile(const char* name, const char* source, int32_t d, int32_t n_params, const char* include_dir,
                      int32_t* rhs_id);
 

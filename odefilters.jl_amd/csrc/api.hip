@@ -274,8 +274,8 @@ int odef_create(odef_ctx** out, const odef_config* cfg) {
   if (cfg->diffusion != ODEF_DIFFUSION_DYNAMIC && cfg->diffusion != ODEF_DIFFUSION_FIXED)
     return fail(nullptr, "odef_create: unknown diffusion model %d", cfg->diffusion);
   if (cfg->n_traj <= 0) return fail(nullptr, "odef_create: n_traj must be positive");
-  if (cfg->rhs_id >= kJitFirstId && cfg->d * (cfg->order + 1) > 15)
-    return fail(nullptr, "odef_create: run-time compiled vector fields use the lane-per-trajectory kernels, state dimension d(q+1) <= 15 (got %d)", cfg->d * (cfg->order + 1));
+  if (cfg->rhs_id >= kJitFirstId && cfg->d * (cfg->order + 1) > 20)
+    return fail(nullptr, "odef_create: run-time compiled vector fields use the lane-per-trajectory kernels, state dimension d(q+1) <= 20 (got %d)", cfg->d * (cfg->order + 1));
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, "odef_create: no HIP device available (libodefilter_hip has no CPU path)");
@@ -620,7 +620,13 @@ int odef_smooth(odef_ctx* c) {
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   int rc;
   if (c->jit)
-    rc = c->jit->posterior ? jit_launch(S.adaptive ? c->jit->smooth_adapt : c->jit->smooth_fixed, (unsigned)((S.N + 63) / 64), 1, &S, c->stream) : -3;
+    if (c->jit->posterior)
+      rc = jit_launch(S.adaptive ? c->jit->smooth_adapt : c->jit->smooth_fixed, (unsigned)((S.N + 63) / 64), 1, &S, c->stream);
+    else if (c->jit->smooth_rows) {
+      const long tpb = 64 / c->jit->rows_team;
+      rc = jit_launch(c->jit->smooth_rows, (unsigned)((S.N + tpb - 1) / tpb), 1, &S, c->stream);
+    } else
+      rc = -3;
   else
     rc = c->team_path ? launch_smooth_d28(c->q, S, c->d_ws, c->stream) : launch_smooth(c->d, c->q, S, c->stream);
   if (rc) return fail(c, "odef_smooth: no kernel for d %d order %d", c->d, c->q);

@@ -12,7 +12,9 @@ struct JitModule {
   hipModule_t mod = nullptr;
   hipFunction_t fixed_every = nullptr, fixed_final = nullptr, adaptive = nullptr;
   hipFunction_t smooth_fixed = nullptr, smooth_adapt = nullptr, dense = nullptr, sample = nullptr;
-  bool posterior = false;  // smoother / dense output / sampler available (state dimension <= 12)
+  hipFunction_t smooth_rows = nullptr;  // 12 < state dimension <= 32: row-per-lane team smoother
+  int rows_team = 16;                   // lanes per trajectory of that kernel
+  bool posterior = false;  // lane smoother / dense output / sampler available (state dimension <= 12)
 };
 
 // returns the new rhs id (>= kJitFirstId) or -1 with the compiler log in `err`

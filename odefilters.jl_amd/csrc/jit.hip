@@ -3,11 +3,17 @@
 // (src/perform_step.jl:106,116-121).  A device kernel cannot call back into the host, so a user vector field is
 // handed over as SOURCE: a struct with the interface of the compiled-in registry (csrc/rhs.h) -- f generic in the
 // scalar type, so that the same text serves the step (double) and the Taylor-mode initialisation (truncated jets,
-// src/state_initialization.jl:2-53), plus the analytic Jacobian for EK1.  hiprtc compiles the very same lane
-// functions (ek_lane.h, smooth_lane.h, dense_lane.h, sample_lane.h) around it for gfx950; the kernels are loaded
-// with the module API and launched with the same parameter structs as the compiled-in ones.
+// src/state_initialization.jl:2-53), plus the analytic Jacobian for EK1 (optional).  hipcc compiles the very same lane
+// functions (ek_lane.h, smooth_lane.h, dense_lane.h, sample_lane.h, smooth_rows.h) around it for gfx950; the
+// kernels are loaded with the module API and launched with the same parameter structs as the compiled-in ones.
 #include <hip/hip_runtime.h>
-#include <hip/hiprtc.h>
+
+#include <fcntl.h>
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <cerrno>
 
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +25,8 @@
 #include <vector>
 
 #include "jit.h"
+
+extern char** environ;
 
 namespace odef {
 namespace {
@@ -46,6 +54,8 @@ std::string translation_unit(const JitRhs& r, int q, int ek1, bool with_posterio
   std::string s;
   s += "#include \"ek_lane.h\"\n";
   if (with_posterior_kernels) s += "#include \"smooth_lane.h\"\n#include \"dense_lane.h\"\n#include \"sample_lane.h\"\n";
+  const bool rows_smoother = !with_posterior_kernels && D <= 32;  // 12 < D <= 32: the row-per-lane team smoother
+  if (rows_smoother) s += "#include \"smooth_rows.h\"\n";
   s += "namespace odef {\n";
   s += r.source;
   s += "\nusing RhsJit = " + r.name + ";\n";
@@ -87,35 +97,95 @@ std::string translation_unit(const JitRhs& r, int q, int ek1, bool with_posterio
          "  const long n_hi = P.adaptive ? wave_uniform_max(valid ? (long)P.nsaved[i] : 0, valid) : P.n_save;\n"
          "  if (valid) sample_lane<" + DD + ", " + Q + ">(P, i, (long)blockIdx.y, xl, n_hi);\n}\n";
   }
+  if (rows_smoother) {
+    const std::string TEAM = D <= 16 ? "16" : "32";
+    s += "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void odef_jit_smooth_rows(const SmoothParams P) {\n"
+         "  constexpr int TEAM = " + TEAM + ", TPB = 64 / TEAM;\n"
+         "  using W = RowsWs<" + DD + ", " + Q + " + 1>;\n"
+         "  __shared__ double lds[TPB * W::size];\n"
+         "  const int team = threadIdx.x / TEAM, tid = threadIdx.x % TEAM;\n"
+         "  const long i = (long)blockIdx.x * TPB + team;\n"
+         "  RowState<" + DD + " * (" + Q + " + 1)> st;\n"
+         "  if (i < P.N) smooth_rows_lane<" + DD + ", " + Q + ", TEAM>(P, i, tid, lds + team * W::size, &st);\n}\n";
+  }
   s += "}  // namespace odef\n";
   return s;
 }
 
-// hiprtc compile -> code object; on failure `err` holds the compiler log
+// Source -> gfx950 code object; on failure `err` holds the compiler log.
+// The compiler runs as a CHILD PROCESS (hipcc --genco), not in-process through hiprtc: hiprtc/comgr of ROCm 7.2 aborts
+// the whole host process ("LLVM ERROR: Unsupported instruction") on the larger lane kernels (state dimension 14 and
+// up), which the offline compiler builds without complaint; a child process can only fail with a log.
+// $ODEFILTER_HIP_HIPCC overrides the compiler path (default: hipcc on PATH, then /opt/rocm/bin/hipcc).
+std::string read_file(const std::string& path) {
+  std::string out;
+  if (FILE* f = fopen(path.c_str(), "rb")) {
+    char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    fclose(f);
+  }
+  return out;
+}
+
 bool compile(const std::string& src, const std::string& include_dir, std::vector<char>& code, std::string& err) {
-  hiprtcProgram prog;
-  if (hiprtcCreateProgram(&prog, src.c_str(), "odef_user_rhs.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
-    err = "hiprtcCreateProgram failed";
+  char tmpl[] = "/tmp/odef_jit_XXXXXX";
+  const char* dir = mkdtemp(tmpl);
+  if (!dir) {
+    err = "odef_rhs_compile: cannot create a temporary directory under /tmp";
     return false;
+  }
+  const std::string base = dir, srcp = base + "/rhs.hip", outp = base + "/rhs.co", logp = base + "/log.txt";
+  if (FILE* f = fopen(srcp.c_str(), "wb")) {
+    fwrite(src.data(), 1, src.size(), f);
+    fclose(f);
   }
   const std::string inc = "-I" + (include_dir.empty() ? default_include_dir() : include_dir);
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++20", inc.c_str()};
-  const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
-  if (r != HIPRTC_SUCCESS) {
-    size_t n = 0;
-    hiprtcGetProgramLogSize(prog, &n);
-    std::string log(n + 1, '\0');
-    if (n) hiprtcGetProgramLog(prog, &log[0]);
-    err = std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log.c_str();
-    hiprtcDestroyProgram(&prog);
-    return false;
+  const char* env_cc = getenv("ODEFILTER_HIP_HIPCC");
+  const char* candidates[] = {env_cc ? env_cc : "hipcc", "/opt/rocm/bin/hipcc"};
+  int status = -1;
+  bool spawned = false;
+  for (const char* cc : candidates) {
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 1, logp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    posix_spawn_file_actions_adddup2(&fa, 1, 2);
+    const char* argv[] = {cc, "--offload-arch=gfx950", "-O3", "-std=c++20", "--genco", "-fno-crash-diagnostics", inc.c_str(), srcp.c_str(), "-o", outp.c_str(), nullptr};
+    pid_t pid = 0;
+    const int rc = posix_spawnp(&pid, cc, &fa, nullptr, const_cast<char* const*>(argv), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (rc != 0) continue;
+    spawned = true;
+    while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {
+    }
+    if (WIFEXITED(status) && WEXITSTATUS(status) == 127) {  // exec failed inside the child: try the next candidate
+      spawned = false;
+      continue;
+    }
+    break;
   }
-  size_t n = 0;
-  hiprtcGetCodeSize(prog, &n);
-  code.resize(n);
-  hiprtcGetCode(prog, code.data());
-  hiprtcDestroyProgram(&prog);
-  return true;
+  bool ok = spawned && WIFEXITED(status) && WEXITSTATUS(status) == 0;
+  if (ok) {
+    const std::string co = read_file(outp);
+    ok = !co.empty();
+    code.assign(co.begin(), co.end());
+  }
+  if (!ok) {
+    if (!spawned) {
+      err = "odef_rhs_compile: cannot start hipcc (set ODEFILTER_HIP_HIPCC)";
+    } else {
+      const std::string log = read_file(logp);
+      err = "hipcc: compilation of the user vector field failed\n";
+      if (log.find("illegal VGPR to SGPR copy") != std::string::npos || log.find("ran out of registers") != std::string::npos)
+        err += "(the lane-per-trajectory kernels keep the whole filter state of a trajectory in registers; this state dimension does not fit)\n";
+      err += log.substr(0, 6000);
+    }
+  }
+  remove(srcp.c_str());
+  remove(outp.c_str());
+  remove(logp.c_str());
+  rmdir(dir);
+  return ok;
 }
 
 }  // namespace
@@ -160,6 +230,7 @@ JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& e
   const JitRhs& r = g_rhs[k];
   auto m = std::make_unique<JitModule>();
   m->posterior = r.d * (q + 1) <= 12;  // the lane smoother / dense output / sampler keep a packed matrix per lane in LDS
+  m->rows_team = r.d * (q + 1) <= 16 ? 16 : 32;
   std::vector<char> code;
   if (!compile(translation_unit(r, q, ek1, m->posterior), r.include_dir, code, err)) return nullptr;
   if (hipModuleLoadData(&m->mod, code.data()) != hipSuccess) {
@@ -170,7 +241,8 @@ JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& e
       {&m->fixed_every, "odef_jit_fixed_every", true},   {&m->fixed_final, "odef_jit_fixed_final", true},
       {&m->adaptive, "odef_jit_adaptive", true},         {&m->smooth_fixed, "odef_jit_smooth_fixed", m->posterior},
       {&m->smooth_adapt, "odef_jit_smooth_adapt", m->posterior}, {&m->dense, "odef_jit_dense", m->posterior},
-      {&m->sample, "odef_jit_sample", m->posterior}};
+      {&m->sample, "odef_jit_sample", m->posterior},
+      {&m->smooth_rows, "odef_jit_smooth_rows", !m->posterior && r.d * (q + 1) <= 32}};
   for (auto& e : fn) {
     if (!e.need) continue;
     if (hipModuleGetFunction(e.f, m->mod, e.name) != hipSuccess) {

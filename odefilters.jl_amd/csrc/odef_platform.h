@@ -10,8 +10,8 @@
 #define __host__
 using std::fabs; using std::fmax; using std::fmin; using std::sqrt; using std::pow; using std::log; using std::exp;
 #elif defined(__HIPCC_RTC__)
-// hiprtc (run-time compilation of a user vector field, csrc/jit.hip): the HIP device API and the math
-// functions are built in and there are no system headers; the few traits the math headers use are declared here.
+// hiprtc-style compilation without system headers (kept working although csrc/jit.hip now uses a hipcc child
+// process): the HIP device API and the math functions are built in; the few traits the math headers use are declared here.
 namespace std {
 template <class T, T v>
 struct integral_constant {

@@ -517,7 +517,7 @@ def _l96_field():
 
 
 def test_user_vector_field_equals_the_compiled_in_one(pkg):
-    """The same Lorenz-63 text through odef_rhs_compile (hiprtc) and through the compiled-in registry: identical
+    """The same Lorenz-63 text through odef_rhs_compile (hipcc child process) and through the compiled-in registry: identical
     kernels source, so identical results -- fixed grid + smoother, adaptive, dense output, sampling."""
     pkg.compile_rhs("UserLorenz", USER_LORENZ, 3, 3)
     vf = orc.vector_field("lorenz63")
@@ -540,6 +540,47 @@ def test_user_vector_field_equals_the_compiled_in_one(pkg):
         np.testing.assert_allclose(b(tq)[0][..., :3], a(tq)[0][..., :3], rtol=1e-11, atol=0)
         sa, sb = a.sample_states(3, 7)[:, :, :3], b.sample_states(3, 7)[:, :, :3]
         assert np.abs(sb - sa).max() <= 1e-8 * np.abs(sa).max()
+
+
+USER_L96_5 = """
+struct UserL96five {
+  static constexpr int d = 5, np = 1;
+  template <class T>
+  __device__ static void f(const T (&u)[5], const double* p, T (&du)[5]) {
+    for (int i = 0; i < 5; ++i) du[i] = (u[(i + 1) % 5] - u[(i + 3) % 5]) * u[(i + 4) % 5] - u[i] + p[0];
+  }
+};
+"""
+
+
+def test_user_vector_field_state_dimension_15(pkg):
+    """d = 5, order 2 (D = 15): the lane filter plus the row-team smoother, both run-time compiled; EK1 with the
+    forward-mode Jacobian."""
+    pkg.compile_rhs("UserL96five", USER_L96_5, 5, 1)
+
+    def f(u, p, t):
+        return [(u[(i + 1) % 5] - u[(i + 3) % 5]) * u[(i + 4) % 5] - u[i] + p[0] for i in range(5)]
+
+    def jac(u, p, t):
+        J = np.zeros((5, 5))
+        for i in range(5):
+            ip, im2, im1 = (i + 1) % 5, (i + 3) % 5, (i + 4) % 5
+            J[i, ip] += u[im1]
+            J[i, im2] -= u[im1]
+            J[i, im1] += u[ip] - u[im2]
+            J[i, i] -= 1.0
+        return J
+
+    vf = orc.VectorField("l96five", 100, 5, 1, f, jac, np.array([1.0, 2.0, 0.5, -1.0, 0.3]), np.array([8.0]), (0.0, 0.2))
+    prob = pkg.ODEProblem("UserL96five", vf.u0, vf.tspan, vf.p)
+    sol = pkg.solve(prob, pkg.EK1(order=2), dt=2.0**-7, adaptive=False)
+    assert sol.retcode == ["Success"]
+    ref = orc.solve(vf, orc.EK1(order=2), tspan=vf.tspan, dt=2.0**-7)
+    np.testing.assert_allclose(sol.x_filt_mean()[0][:, :5], ref.means(smoothed=False)[:, :5], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(sol.u[0], ref.u, rtol=1e-9, atol=1e-13)
+    assert P.cov_err(sol.x_smooth_cov()[0], ref.covs(smoothed=True)) < 1e-5
+    with pytest.raises(pkg.OdefError, match="state dimension <= 12"):
+        sol(np.array([0.1]))
 
 
 def test_user_vector_field_without_jacobian_uses_forward_mode(pkg):
