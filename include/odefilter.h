@@ -151,8 +151,8 @@ const char* odef_last_error(const odef_ctx* ctx); /* ctx may be NULL: last error
  * own lane kernels around it for gfx950 (include_dir = directory holding the csrc headers; NULL: $ODEFILTER_HIP_INCLUDE
  * or the build-time location).  Returns 0 and a new rhs id (>= 100) for
  * odef_config.rhs_id; on a compile error returns -1 and odef_last_error(NULL) holds the compiler log.
- * Filter and smoother: d(q+1) <= 20 as far as the kernels fit the register file (a dimension that does not is rejected
- * here, with the log); dense output and sampling: d(q+1) <= 12. */
+ * Filter and smoother: d <= 10 and d(q+1) <= 20; dense output and sampling: d(q+1) <= 12.  Whatever the compiler
+ * rejects comes back as an error with its log. */
 int odef_rhs_compile(const char* name, const char* source, int32_t d, int32_t n_params, const char* include_dir,
                      int32_t* rhs_id);
 

@@ -73,8 +73,12 @@ struct RowStore {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, ODEF_STORE_AUX);
     soff += step;
+#ifndef ODEF_ROWSTORE_FREE_OFFSET
     asm volatile("" : "+s"(soff));  // keep the row offset a running scalar (one s_add per store) instead of
                                     // dozens of hoisted loop-invariant offsets that would spill the SGPR file
+                                    // (ODEF_ROWSTORE_FREE_OFFSET: run-time compiled kernels of large state dimension,
+                                    // where pinning it to an SGPR makes the register allocator give up)
+#endif
   }
 };
 #endif

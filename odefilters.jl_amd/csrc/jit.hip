@@ -52,6 +52,7 @@ std::string default_include_dir() {
 std::string translation_unit(const JitRhs& r, int q, int ek1, bool with_posterior_kernels) {
   const int D = r.d * (q + 1);
   std::string s;
+  if (D > 12) s += "#define ODEF_ROWSTORE_FREE_OFFSET 1\n";  // see RowStore (ek_lane.h)
   s += "#include \"ek_lane.h\"\n";
   if (with_posterior_kernels) s += "#include \"smooth_lane.h\"\n#include \"dense_lane.h\"\n#include \"sample_lane.h\"\n";
   const bool rows_smoother = !with_posterior_kernels && D <= 32;  // 12 < D <= 32: the row-per-lane team smoother
@@ -195,8 +196,8 @@ int jit_register(const char* name, const char* source, int d, int np, const char
     err = "odef_rhs_compile: null or empty name/source";
     return -1;
   }
-  if (d < 1 || d > 16 || np < 0) {
-    err = "odef_rhs_compile: d must be in 1..16 and n_params >= 0";
+  if (d < 1 || d > 10 || np < 0) {
+    err = "odef_rhs_compile: d must be in 1..10 (the lane kernels handle d(q+1) <= 20) and n_params >= 0";
     return -1;
   }
   JitRhs r{name, source, include_dir ? include_dir : "", d, np};

@@ -542,41 +542,45 @@ def test_user_vector_field_equals_the_compiled_in_one(pkg):
         assert np.abs(sb - sa).max() <= 1e-8 * np.abs(sa).max()
 
 
-USER_L96_5 = """
-struct UserL96five {
-  static constexpr int d = 5, np = 1;
+def _l96_source(name, d):
+    return f"""
+struct {name} {{
+  static constexpr int d = {d}, np = 1;
   template <class T>
-  __device__ static void f(const T (&u)[5], const double* p, T (&du)[5]) {
-    for (int i = 0; i < 5; ++i) du[i] = (u[(i + 1) % 5] - u[(i + 3) % 5]) * u[(i + 4) % 5] - u[i] + p[0];
-  }
-};
+  __device__ static void f(const T (&u)[{d}], const double* p, T (&du)[{d}]) {{
+    for (int i = 0; i < {d}; ++i) du[i] = (u[(i + 1) % {d}] - u[(i + {d - 2}) % {d}]) * u[(i + {d - 1}) % {d}] - u[i] + p[0];
+  }}
+}};
 """
 
 
-def test_user_vector_field_state_dimension_15(pkg):
-    """d = 5, order 2 (D = 15): the lane filter plus the row-team smoother, both run-time compiled; EK1 with the
-    forward-mode Jacobian."""
-    pkg.compile_rhs("UserL96five", USER_L96_5, 5, 1)
+@pytest.mark.parametrize("d,q", [(5, 2), (8, 1)])
+def test_user_vector_field_larger_state(pkg, d, q):
+    """Lorenz-96 with d variables, D = d(q+1) = 15 / 16: the lane filter plus the row-team smoother, both run-time
+    compiled; EK1 with the forward-mode Jacobian."""
+    name = f"UserL96d{d}"
+    pkg.compile_rhs(name, _l96_source(name, d), d, 1)
 
     def f(u, p, t):
-        return [(u[(i + 1) % 5] - u[(i + 3) % 5]) * u[(i + 4) % 5] - u[i] + p[0] for i in range(5)]
+        return [(u[(i + 1) % d] - u[(i + d - 2) % d]) * u[(i + d - 1) % d] - u[i] + p[0] for i in range(d)]
 
     def jac(u, p, t):
-        J = np.zeros((5, 5))
-        for i in range(5):
-            ip, im2, im1 = (i + 1) % 5, (i + 3) % 5, (i + 4) % 5
+        J = np.zeros((d, d))
+        for i in range(d):
+            ip, im2, im1 = (i + 1) % d, (i + d - 2) % d, (i + d - 1) % d
             J[i, ip] += u[im1]
             J[i, im2] -= u[im1]
             J[i, im1] += u[ip] - u[im2]
             J[i, i] -= 1.0
         return J
 
-    vf = orc.VectorField("l96five", 100, 5, 1, f, jac, np.array([1.0, 2.0, 0.5, -1.0, 0.3]), np.array([8.0]), (0.0, 0.2))
-    prob = pkg.ODEProblem("UserL96five", vf.u0, vf.tspan, vf.p)
-    sol = pkg.solve(prob, pkg.EK1(order=2), dt=2.0**-7, adaptive=False)
+    u0 = np.array([1.0, 2.0, 0.5, -1.0, 0.3, 1.5, -0.7, 0.9])[:d]
+    vf = orc.VectorField(name, 100, d, 1, f, jac, u0, np.array([8.0]), (0.0, 0.2))
+    prob = pkg.ODEProblem(name, vf.u0, vf.tspan, vf.p)
+    sol = pkg.solve(prob, pkg.EK1(order=q), dt=2.0**-7, adaptive=False)
     assert sol.retcode == ["Success"]
-    ref = orc.solve(vf, orc.EK1(order=2), tspan=vf.tspan, dt=2.0**-7)
-    np.testing.assert_allclose(sol.x_filt_mean()[0][:, :5], ref.means(smoothed=False)[:, :5], rtol=1e-10, atol=1e-13)
+    ref = orc.solve(vf, orc.EK1(order=q), tspan=vf.tspan, dt=2.0**-7)
+    np.testing.assert_allclose(sol.x_filt_mean()[0][:, :d], ref.means(smoothed=False)[:, :d], rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(sol.u[0], ref.u, rtol=1e-9, atol=1e-13)
     assert P.cov_err(sol.x_smooth_cov()[0], ref.covs(smoothed=True)) < 1e-5
     with pytest.raises(pkg.OdefError, match="state dimension <= 12"):
