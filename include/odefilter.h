@@ -24,6 +24,7 @@
  *                                                                                src/smoothing.jl:4-63
  *   odef_dense_output               sol(t), GaussianODEFilterPosterior            src/solution.jl:165-214
  *   odef_sample                     sample_states / sample                        src/solution_sampling.jl:15-62
+ *   odef_dense_sample               dense_sample_states / dense_sample            src/solution_sampling.jl:63-75
  *   odef_rhs_compile                the user's f / f.jac closure (compiled, not called) src/perform_step.jl:106,116-121
  *   odef_get / odef_get_device      sol.t, sol.x_filt, sol.x_smooth, sol.diffusions, sol.log_likelihood,
  *                                   sol.destats, sol.retcode                     src/solution.jl:8-24
@@ -197,6 +198,13 @@ int odef_dense_output(odef_ctx* ctx, const double* tq, int64_t n_q, int smoothed
  * oracle/odefilter_oracle.py sample_normal); noise_scale = 1 gives samples, 0 the chain of conditional means.
  * Result in ODEF_F_SAMPLES; sample(sol, n) of the reference is its rows 0..d-1.  State dimension <= 12. */
 int odef_sample(odef_ctx* ctx, int64_t n_samples, uint64_t seed, double noise_scale);
+
+/* Posterior sampling on a dense grid (dense_sample_states / dense_sample, src/solution_sampling.jl:63-75): the FILTER
+ * posterior is interpolated at the n_q host times tq (as odef_dense_output with smoothed = 0; the reference uses
+ * range(t0, t_end, length = 1000)) and the backward sampler of odef_sample runs over those states, the diffusion
+ * of an interval looked up by time (:41).  Overwrites ODEF_F_DENSE_MEAN / ODEF_F_DENSE_COV_TRIL; result in
+ * ODEF_F_SAMPLES as [n_q][D][n_samples][N].  tq must be non-decreasing and >= t0.  State dimension <= 12. */
+int odef_dense_sample(odef_ctx* ctx, const double* tq, int64_t n_q, int64_t n_samples, uint64_t seed, double noise_scale);
 
 int64_t odef_n_save(const odef_ctx* ctx); /* leading dimension of MEAN/COV_TRIL/DIFFUSION/T */
 int odef_field_bytes(const odef_ctx* ctx, int field, size_t* bytes);

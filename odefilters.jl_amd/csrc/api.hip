@@ -722,6 +722,40 @@ int odef_sample(odef_ctx* c, int64_t n_samples, uint64_t seed, double noise_scal
   return 0;
 }
 
+int odef_dense_sample(odef_ctx* c, const double* tq, int64_t n_q, int64_t n_samples, uint64_t seed, double noise_scale) {
+  if (!c || !tq) return fail(c, "odef_dense_sample: null argument");
+  if (n_samples < 1 || n_samples > 65535) return fail(c, "odef_dense_sample: n_samples must be in 1..65535");
+  for (int64_t k = 1; k < n_q; ++k)
+    if (!(tq[k] >= tq[k - 1])) return fail(c, "odef_dense_sample: times must be non-decreasing");
+  if (odef_dense_output(c, tq, n_q, 0)) return -1;  // filter posterior at tq (src/solution_sampling.jl:66)
+  c->n_samples = (long)n_samples;
+  if (ensure(c, ODEF_F_SAMPLES, field_count(c, ODEF_F_SAMPLES, (long)n_q) * sizeof(double))) return -1;
+  SampleParams S;
+  std::memset(&S, 0, sizeof S);
+  S.pc = c->pc;
+  S.N = c->cfg.n_traj;
+  S.n_save = (long)n_q;
+  S.adaptive = c->adaptive;
+  S.tsave = (const double*)c->f[ODEF_F_T].ptr;
+  S.nsaved = (const int*)c->f[ODEF_F_NSAVED].ptr;
+  S.mean = (const double*)c->f[ODEF_F_DENSE_MEAN].ptr;
+  S.cov = (const double*)c->f[ODEF_F_DENSE_COV_TRIL].ptr;
+  S.diff = (const double*)c->f[ODEF_F_DIFFUSION].ptr;
+  S.tq = c->d_tq;
+  S.rec_t = c->d_tgrid;
+  S.n_rec = c->n_save;
+  S.n_samples = (long)n_samples;
+  S.seed = (unsigned long long)seed;
+  S.noise_scale = noise_scale;
+  S.samples = (double*)c->f[ODEF_F_SAMPLES].ptr;
+  const int rc = c->jit ? (c->jit->posterior ? jit_launch(c->jit->sample, (unsigned)((S.N + 63) / 64), (unsigned)S.n_samples, &S, c->stream) : -3)
+                 : c->d == 2 ? launch_sample_d2(c->q, S, c->stream) : c->d == 3 ? launch_sample_d3(c->q, S, c->stream) : -3;
+  if (rc) return fail(c, "odef_dense_sample: no kernel for d %d order %d", c->d, c->q);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int64_t odef_n_save(const odef_ctx* c) { return c ? c->n_save : -1; }
 
 int odef_field_bytes(const odef_ctx* c, int field, size_t* bytes) {

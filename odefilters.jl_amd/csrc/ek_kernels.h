@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kWave) void sample_kernel(const SampleParams P) {
   const long i = (long)blockIdx.x * kWave + threadIdx.x;
   const LaneMem xl{lds + threadIdx.x, kWave};
   const bool valid = i < P.N;
-  const long n_hi = P.adaptive ? wave_uniform_max(valid ? (long)P.nsaved[i] : 0, valid) : P.n_save;
+  const long n_hi = (P.adaptive && !P.tq) ? wave_uniform_max(valid ? (long)P.nsaved[i] : 0, valid) : P.n_save;
   if (valid) sample_lane<d, q>(P, i, (long)blockIdx.y, xl, n_hi);
 }
 struct LaunchSample {

@@ -95,7 +95,7 @@ std::string translation_unit(const JitRhs& r, int q, int ek1, bool with_posterio
          "  const long i = (long)blockIdx.x * 64 + threadIdx.x;\n"
          "  const LaneMem xl{lds + threadIdx.x, 64};\n"
          "  const bool valid = i < P.N;\n"
-         "  const long n_hi = P.adaptive ? wave_uniform_max(valid ? (long)P.nsaved[i] : 0, valid) : P.n_save;\n"
+         "  const long n_hi = (P.adaptive && !P.tq) ? wave_uniform_max(valid ? (long)P.nsaved[i] : 0, valid) : P.n_save;\n"
          "  if (valid) sample_lane<" + DD + ", " + Q + ">(P, i, (long)blockIdx.y, xl, n_hi);\n}\n";
   }
   if (rows_smoother) {

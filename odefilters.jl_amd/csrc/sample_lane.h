@@ -1,4 +1,4 @@
-// Posterior sampling on the saved grid (src/solution_sampling.jl:24-62).
+// Posterior sampling on the saved grid (src/solution_sampling.jl:24-62) and on a dense grid (:63-75).
 // One lane per (sample, trajectory): x_N ~ N(mu_N, S_N); backwards x_i ~ smooth(x_filt[i], delta(x_{i+1}))
 // in preconditioned coordinates, i.e. the RTS step core with a zero "next" covariance, followed by
 // mean + L xi with L the lower-triangular factor of the un-preconditioned conditional covariance (the
@@ -27,6 +27,12 @@ struct SampleParams {
   long n_samples;
   unsigned long long seed;
   double noise_scale;   // 1: samples; 0: the chain of conditional means (test hook)
+  // dense-grid mode (dense_sample_states, src/solution_sampling.jl:63-69): tq != nullptr.  mean/cov are then the
+  // FILTER posterior interpolated at the n_save shared times tq (dense_output_kernel), diff stays the solver's
+  // record array, and the diffusion of an interval is looked up by time (:41) in the record times.
+  const double* tq;     // [n_save]
+  const double* rec_t;  // fixed solves: [n_rec] record times (adaptive solves: tsave / nsaved)
+  long n_rec;
   double* samples;      // [n_save][D][n_samples][N]
 };
 
@@ -71,7 +77,8 @@ template <int d, int q>
 __device__ inline void sample_lane(const SampleParams& P, long i, long j, const LaneMem& xl, long n_hi) {
   constexpr int NB = q + 1, D = d * NB, TRI = D * (D + 1) / 2;
   const size_t N = (size_t)P.N, NS = (size_t)P.n_samples;
-  const long n = P.adaptive ? (long)P.nsaved[i] : P.n_save;
+  const bool dense = P.tq != nullptr;
+  const long n = (P.adaptive && !dense) ? (long)P.nsaved[i] : P.n_save;
   const PriorConsts& pc = P.pc;
   auto out = [&](long s, int k) -> double& { return P.samples[(((size_t)s * D + k) * NS + (size_t)j) * N + i]; };
   auto ctr = [&](long s) { return (((unsigned long long)i * NS + (unsigned long long)j) * (unsigned long long)P.n_save + (unsigned long long)s) * (unsigned long long)D; };
@@ -89,8 +96,8 @@ __device__ inline void sample_lane(const SampleParams& P, long i, long j, const 
   for (long s = n_hi - 2; s >= 0; --s) {  // wave-uniform slot, see wave_uniform_max (smooth_lane.h)
     if (s > n - 2) continue;
     double h, pj[NB], pij[NB];
-    if (P.adaptive) {
-      h = P.tsave[(size_t)(s + 1) * N + i] - P.tsave[(size_t)s * N + i];
+    if (P.adaptive || dense) {
+      h = dense ? P.tq[s + 1] - P.tq[s] : P.tsave[(size_t)(s + 1) * N + i] - P.tsave[(size_t)s * N + i];
       double val = (h != 0.0) ? precond_val<q>(h) : 1.0;
 #pragma unroll
       for (int J = 0; J < NB; ++J) {
@@ -112,7 +119,21 @@ __device__ inline void sample_lane(const SampleParams& P, long i, long j, const 
       for (int k = 0; k < D; ++k) out(s, k) = xs[k];
       continue;
     }
-    const double sigma2 = P.diff[(size_t)(s + 1) * N + i];
+    long sd = s + 1;  // slot k holds the diffusion of the step k-1 -> k
+    if (dense) {      // i_diffusion = sum(difftimes .<= ts[i]) (src/solution_sampling.jl:41), by bisection
+      const long nrec = P.adaptive ? (long)P.nsaved[i] : P.n_rec;
+      const double tval = P.tq[s];
+      long lo = 0, hi = nrec;
+      while (lo < hi) {
+        const long mid = (lo + hi) / 2;
+        const double tm = P.adaptive ? P.tsave[(size_t)mid * N + i] : P.rec_t[mid];
+        if (tm <= tval) lo = mid + 1;
+        else hi = mid;
+      }
+      sd = lo < nrec - 1 ? lo : nrec - 1;
+      if (sd < 1) sd = nrec > 1 ? 1 : 0;
+    }
+    const double sigma2 = P.diff[(size_t)sd * N + i];
     // all loads of the step first, arithmetic afterwards (see smooth_lane_v2)
     double mt[D], B[TRI], Cs[TRI], msn[D], mc[D];
     {

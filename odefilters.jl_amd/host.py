@@ -68,6 +68,7 @@ SYMBOLS = {
     "odef_smooth": (C.c_int, [_vp]),
     "odef_dense_output": (C.c_int, [_vp, _dp, C.c_int64, C.c_int]),
     "odef_sample": (C.c_int, [_vp, C.c_int64, C.c_uint64, C.c_double]),
+    "odef_dense_sample": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_uint64, C.c_double]),
     "odef_n_save": (C.c_int64, [_vp]),
     "odef_field_bytes": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_size_t)]),
     "odef_get": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
@@ -232,6 +233,16 @@ class Context:
         a = np.empty(nb // 8)
         self._chk(self.lib.odef_get(self._h, F_SAMPLES, a.ctypes.data_as(_vp), nb))
         return a.reshape(self.n_save, self.D, int(n), self.N)
+
+    def dense_sample_states(self, tq, n: int, seed: int, noise_scale: float = 1.0):
+        """n joint draws of the state path on the times tq (filter-interpolated states): [n_q, D, n, N]."""
+        tq = np.ascontiguousarray(tq, float)
+        self._chk(self.lib.odef_dense_sample(self._h, tq.ctypes.data_as(C.POINTER(C.c_double)), len(tq), int(n),
+                                             int(seed) & 0xFFFFFFFFFFFFFFFF, float(noise_scale)))
+        nb = self.field_bytes(F_SAMPLES)
+        a = np.empty(nb // 8)
+        self._chk(self.lib.odef_get(self._h, F_SAMPLES, a.ctypes.data_as(_vp), nb))
+        return a.reshape(len(tq), self.D, int(n), self.N)
 
     def synchronize(self):
         self._chk(self.lib.odef_synchronize(self._h))
@@ -544,6 +555,23 @@ class EnsembleSolution:
     def sample(self, n: int = 1, seed: int = 0x5A3B1E) -> np.ndarray:
         """`sample(sol, n)` (src/solution_sampling.jl:19-23): [N, n_save, d, n]."""
         return self.sample_states(n, seed)[:, :, : self.d, :]
+
+    def dense_sample_states(self, n: int = 1, seed: int = 0x5A3B1E, times=None, noise_scale: float = 1.0):
+        """`dense_sample_states(sol, n)` (src/solution_sampling.jl:63-69): ([N, n_t, D, n], times); the reference's
+        grid is range(t0, t_end, length=1000), any non-decreasing `times` in [t0, t_end] may be given instead."""
+        if not self.smoothed:
+            raise AssertionError("sampling not implemented for non-smoothed posteriors")
+        if times is None:
+            t = self.t
+            t0, t_end = (t[0, 0], t[0, self.nsaved[0] - 1]) if self.adaptive else (t[0], t[-1])
+            times = np.linspace(float(t0), float(t_end), 1000)
+        times = np.ascontiguousarray(times, float)
+        return self.ctx.dense_sample_states(times, n, seed, noise_scale).transpose(3, 0, 1, 2), times
+
+    def dense_sample(self, n: int = 1, seed: int = 0x5A3B1E, times=None):
+        """`dense_sample(sol, n)` (src/solution_sampling.jl:70-75): ([N, n_t, d, n], times)."""
+        s, times = self.dense_sample_states(n, seed, times)
+        return s[:, :, : self.d, :], times
 
     @property
     def diffusions(self) -> np.ndarray:

@@ -53,22 +53,41 @@ def filter_fixed(rhs: str, q: int, ek1: bool, u0s: np.ndarray, p: np.ndarray, tg
     return mean, cov, el
 
 
+def effective_cores() -> int:
+    """Host cores this process may actually use: CPU affinity capped by the cgroup CPU quota
+    (a container can see 128 logical CPUs and be granted 16 of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(-(-int(quota) // int(period)))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def bench_lorenz(seconds_budget: float = 15.0):
-    """cpu_baseline leg of bench.py: Lorenz-63 EK1(3), dt = 2^-9, all host cores."""
+    """cpu_baseline leg of bench.py: Lorenz-63 EK1(3), dt = 2^-9, all host cores granted to this process."""
     vf = orc.vector_field("lorenz63")
-    threads = lib().cport_max_threads()
+    threads = max(1, min(lib().cport_max_threads(), effective_cores()))
     nsteps = 1024
     tg = np.arange(nsteps + 1) * 2.0**-9
     n = 16 * threads
     u0s = orc.ensemble_u0(vf.u0, n, 1e-2)
-    _, _, el = filter_fixed("lorenz63", 3, True, u0s, vf.p, tg)  # calibration
+    _, _, el = filter_fixed("lorenz63", 3, True, u0s, vf.p, tg, threads)  # calibration
     n2 = int(max(n, min(65536, n * seconds_budget / max(el, 1e-6) // threads * threads)))
     u0s = orc.ensemble_u0(vf.u0, min(n2, 4096), 1e-2)
     reps = max(1, n2 // len(u0s))
     best = None
     tot = 0.0
     for _ in range(min(reps, 3)):
-        _, _, el = filter_fixed("lorenz63", 3, True, u0s, vf.p, tg)
+        _, _, el = filter_fixed("lorenz63", 3, True, u0s, vf.p, tg, threads)
         tot += el
         best = el if best is None else min(best, el)
     return {"value": len(u0s) * nsteps / best, "unit": "filter steps/s", "cores": threads, "kind": "port",

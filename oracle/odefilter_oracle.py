@@ -884,18 +884,19 @@ def lower_factor(C: np.ndarray) -> np.ndarray:
     return L
 
 
-def sample_states(sol: Solution, consts, n: int = 1, seed: int = 0x5A3B1E, traj: int = 0, sqrt: str = "reference",
-                  noise_scale: float = 1.0, normal=None) -> np.ndarray:
-    """solution_sampling.jl:24-62 on the saved grid: draw x_N ~ N(mu_N, S_N), then backwards
-    x_i ~ smooth(x_filt[i], delta(x_{i+1})) in preconditioned coordinates.  Returns [n_save, D, n].
+def sample_states_on(ts, xs, diffusions, difftimes, consts, n: int = 1, seed: int = 0x5A3B1E, traj: int = 0,
+                     sqrt: str = "reference", noise_scale: float = 1.0, normal=None) -> np.ndarray:
+    """solution_sampling.jl:24-62 for states `xs` at times `ts`: draw x_N ~ N(mu_N, S_N), then backwards
+    x_i ~ smooth(xs[i], delta(x_{i+1})) in preconditioned coordinates.  Returns [len(ts), D, n].
     sqrt = "reference": the square root the reference multiplies the noise with (R' of its QR, :10);
     sqrt = "cholesky":  the lower-triangular factor of the same covariance (what the device uses)."""
     A, Q_L, precond, d, q = consts
     D = d * (q + 1)
-    ts, xs = sol.t, sol.x_filt
     ns = len(xs)
+    assert len(diffusions) + 1 == len(difftimes)  # :25
     normal = normal or (lambda j, slot, k: sample_normal(seed, traj, j, slot, k, n, ns, D))
     path = np.zeros((ns, D, n))
+    difftimes = np.asarray(difftimes, float)
 
     def draw(g: SRGaussian, j: int, slot: int) -> np.ndarray:
         xi = np.array([normal(j, slot, k) for k in range(D)])
@@ -906,7 +907,8 @@ def sample_states(sol: Solution, consts, n: int = 1, seed: int = 0x5A3B1E, traj:
         path[ns - 1, :, j] = draw(xs[-1], j, ns - 1)
     for i in range(ns - 2, -1, -1):  # Julia i = length(xs)-1 .. 1
         dt = ts[i + 1] - ts[i]
-        diffusion = sol.diffusions[i]  # i_diffusion = sum(difftimes .<= ts[i]) (1-based) == step t[i] -> t[i+1]
+        i_diffusion = int(np.sum(difftimes <= ts[i]))  # 1-based (:41)
+        diffusion = diffusions[i_diffusion - 1]
         Qh = apply_diffusion(Q_L, diffusion)
         P = precond(dt)
         PI = 1.0 / P
@@ -920,10 +922,29 @@ def sample_states(sol: Solution, consts, n: int = 1, seed: int = 0x5A3B1E, traj:
     return path
 
 
+def sample_states(sol: Solution, consts, n: int = 1, **kw) -> np.ndarray:
+    """solution_sampling.jl:15-18: on the saved grid, from the filter states."""
+    return sample_states_on(sol.t, sol.x_filt, sol.diffusions, sol.t, consts, n, **kw)
+
+
+def dense_sample_states(sol: Solution, consts, n: int = 1, times=None, **kw):
+    """solution_sampling.jl:63-69: sampling on a dense grid (1 000 points by default) of FILTER-interpolated states."""
+    times = np.linspace(sol.t[0], sol.t[-1], 1000) if times is None else np.asarray(times, float)
+    states = [dense_output(sol, consts, float(t), smoothed=False) for t in times]
+    return sample_states_on(times, states, sol.diffusions, sol.t, consts, n, **kw), times
+
+
 def sample(sol: Solution, consts, n: int = 1, **kw) -> np.ndarray:
     """solution_sampling.jl:19-23: the zeroth-derivative part [n_save, d, n]."""
     d = consts[3]
     return sample_states(sol, consts, n, **kw)[:, :d, :]
+
+
+def dense_sample(sol: Solution, consts, n: int = 1, times=None, **kw):
+    """solution_sampling.jl:70-75: the zeroth-derivative part of dense_sample_states, and the times."""
+    d = consts[3]
+    states, times = dense_sample_states(sol, consts, n, times=times, **kw)
+    return states[:, :d, :], times
 
 
 # --------------------------------------------------------------------------------------

@@ -86,7 +86,7 @@ def unpack_tril(c, D):
 
 def emul_solve(rhs_id, d, q, ek1, u0s, p, *, team=False, tgrid=None, adaptive=False, t0=0.0, t1=1.0, abstol=1e-6, reltol=1e-3,
                dt0=1e-2, max_save=4096, everystep=True, fixed_diffusion=False, want_loglik=True, smooth=False,
-               ctrl=None, dense_t=None, sample=None):
+               ctrl=None, dense_t=None, sample=None, dense_sample=None):
     """u0s [N, d]; p [np] shared.  Returns dict of numpy arrays in the device layout transposed
     to trajectory-major: mean [N, n_save, D], cov [N, n_save, D, D] ..."""
     u0s = np.asarray(u0s, float)
@@ -181,4 +181,24 @@ def emul_solve(rhs_id, d, q, ek1, u0s, p, *, team=False, tgrid=None, adaptive=Fa
         assert rc == 0, rc
         out["qmean"] = qm.transpose(2, 0, 1)
         out["qcov"] = unpack_tril(qc.transpose(2, 0, 1), D)
+    if dense_sample is not None:  # (times, n_samples, seed, noise_scale): filter posterior at the times, then the sampler
+        class EmulDense(C.Structure):
+            _fields_ = [("a", C.POINTER(EmulArgs)), ("smoothed", C.c_int), ("tq", dp), ("n_q", C.c_long), ("qmean", dp), ("qcov", dp)]
+
+        class EmulDenseSample(C.Structure):
+            _fields_ = [("a", C.POINTER(EmulArgs)), ("tq", dp), ("n_q", C.c_long), ("qmean", dp), ("qcov", dp), ("rec_t", dp),
+                        ("n_samples", C.c_long), ("seed", C.c_ulonglong), ("noise_scale", C.c_double), ("samples", dp)]
+        times, ns_, seed_, scale_ = dense_sample
+        tq = np.ascontiguousarray(times, float)
+        qm = np.zeros((len(tq), D, N)); qc = np.zeros((len(tq), TRI, N))
+        if not adaptive:
+            a.hs = _p(tg)
+        e = EmulDense(C.pointer(a), 0, _p(tq), len(tq), _p(qm), _p(qc))
+        rc = lib().emul_dense(C.byref(e), d)
+        assert rc == 0, rc
+        smp = np.zeros((len(tq), D, ns_, N))
+        e2 = EmulDenseSample(C.pointer(a), _p(tq), len(tq), _p(qm), _p(qc), _p(tg), ns_, seed_, scale_, _p(smp))
+        rc = lib().emul_dense_sample(C.byref(e2), d)
+        assert rc == 0, rc
+        out["dense_samples"] = smp.transpose(3, 0, 1, 2)  # [N, n_q, D, n_samples]
     return out

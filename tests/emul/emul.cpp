@@ -208,7 +208,7 @@ struct RunSample {
       constexpr int D = d * (q + 1);
       std::vector<double> x(D * (D + 1) / 2);
       for (long j = 0; j < P.n_samples; ++j)
-        for (long i = 0; i < P.N; ++i) sample_lane<d, q>(P, i, j, LaneMem{x.data(), 1}, P.adaptive ? (long)P.nsaved[i] : P.n_save);
+        for (long i = 0; i < P.N; ++i) sample_lane<d, q>(P, i, j, LaneMem{x.data(), 1}, (P.adaptive && !P.tq) ? (long)P.nsaved[i] : P.n_save);
     }
   }
 };
@@ -222,6 +222,36 @@ extern "C" int emul_sample(const EmulSample* e, int d) {
   P.N = a->N; P.n_save = a->n_save; P.adaptive = a->adaptive;
   P.hs = a->hs; P.ptab = a->ptab; P.tab_idx = a->tab_idx;
   P.tsave = a->tsave; P.nsaved = a->nsaved; P.mean = a->mean; P.cov = a->cov; P.diff = a->diff;
+  P.n_samples = e->n_samples; P.seed = e->seed; P.noise_scale = e->noise_scale; P.samples = e->samples;
+  RunSample r{P};
+  if (d == 2) return dispatch_smooth_order<2>(a->q, r);
+  if (d == 3) return dispatch_smooth_order<3>(a->q, r);
+  return -2;
+}
+
+// dense-grid sampling (sample_lane.h, tq != nullptr): qmean/qcov hold the filter posterior at tq (emul_dense, smoothed = 0)
+struct EmulDenseSample {
+  const EmulArgs* a;
+  const double* tq;
+  long n_q;
+  const double* qmean;
+  const double* qcov;
+  const double* rec_t;  // fixed solves: record times [n_save]
+  long n_samples;
+  unsigned long long seed;
+  double noise_scale;
+  double* samples;  // [n_q][D][n_samples][N]
+};
+extern "C" int emul_dense_sample(const EmulDenseSample* e, int d) {
+  const EmulArgs* a = e->a;
+  SampleParams P;
+  std::memset(&P, 0, sizeof P);
+  std::memcpy(P.pc.At, a->At, sizeof(P.pc.At));
+  std::memcpy(P.pc.Qt, a->Qt, sizeof(P.pc.Qt));
+  std::memcpy(P.pc.QLt, a->QLt, sizeof(P.pc.QLt));
+  P.N = a->N; P.n_save = e->n_q; P.adaptive = a->adaptive;
+  P.tsave = a->tsave; P.nsaved = a->nsaved; P.mean = e->qmean; P.cov = e->qcov; P.diff = a->diff;
+  P.tq = e->tq; P.rec_t = e->rec_t; P.n_rec = a->n_save;
   P.n_samples = e->n_samples; P.seed = e->seed; P.noise_scale = e->noise_scale; P.samples = e->samples;
   RunSample r{P};
   if (d == 2) return dispatch_smooth_order<2>(a->q, r);

@@ -20,7 +20,7 @@ def declared_symbols():
 def test_header_symbols_all_exported(pkg):
     lib = pkg.load_library()
     names = declared_symbols()
-    assert len(names) == 26
+    assert len(names) == 27
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/odefilter.h but not exported"
     # and the Python binding table covers exactly the header

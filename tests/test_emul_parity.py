@@ -226,3 +226,29 @@ def test_posterior_sampling(adaptive):
     assert err[:3].max() < 1e-8 and err.max() < 1e-4, err  # u block / ill-conditioned derivative blocks
     r0 = E.emul_solve(vf.rhs_id, 3, 3, True, vf.u0[None, :], vf.p, smooth=True, sample=(1, seed, 0.0), **kw)
     np.testing.assert_allclose(r0["samples"][0][1:ns, :3, 0], sol.means(smoothed=True)[1:, :3], rtol=1e-7)
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_dense_posterior_sampling(adaptive):
+    """dense_sample_states (src/solution_sampling.jl:63-69): filter posterior interpolated at a dense grid, then the
+    same backward sampler with the diffusion of an interval looked up by time (:41); device source against the oracle
+    with the same N(0,1) stream and square root."""
+    vf = orc.vector_field("lorenz63")
+    alg = orc.EK1(order=3)
+    if adaptive:
+        sol = orc.solve(vf, alg, adaptive=True, dt=2.0**-9, tspan=(0.0, 0.5))
+        kw = dict(adaptive=True, t0=0.0, t1=0.5, dt0=2.0**-9, max_save=256)
+    else:
+        sol = orc.solve(vf, alg, dt=2.0**-6, tspan=(0.0, 0.5))
+        kw = dict(tgrid=np.array(sol.t))
+    consts = orc.make_consts(3, 3)
+    seed, n = 99, 2
+    times = np.linspace(sol.t[0], sol.t[-1], 57)  # off-grid and (first, last) on-grid times
+    r = E.emul_solve(vf.rhs_id, 3, 3, True, vf.u0[None, :], vf.p, smooth=True, dense_sample=(times, n, seed, 1.0), **kw)
+    S = r["dense_samples"][0]
+    assert S.shape == (len(times), 12, n)
+    ref, tt = orc.dense_sample_states(sol, consts, n, times=times, sqrt="cholesky", seed=seed)
+    np.testing.assert_array_equal(tt, times)
+    scale = np.abs(ref).max(axis=(0, 2))[None, :, None]
+    err = (np.abs(S - ref) / scale).max(axis=(0, 2))
+    assert err[:3].max() < 1e-8 and err.max() < 1e-4, err

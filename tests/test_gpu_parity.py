@@ -444,6 +444,37 @@ def test_posterior_sampling(pkg, adaptive):
     assert not np.array_equal(sol.sample_states(n, seed + 1), st)
 
 
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_dense_posterior_sampling(pkg, adaptive):
+    """dense_sample / dense_sample_states (src/solution_sampling.jl:63-75) against the oracle with the same noise stream
+    and square root; shapes as test/solution.jl:74-79, 98-103 (1 000 times by default)."""
+    vf = orc.vector_field("lorenz63")
+    N, t1, n, seed = 70, 0.5, 4, 7
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, (0.0, t1), vf.p), perturb_scale=1e-2)
+    if adaptive:
+        sol = pkg.solve(ens, pkg.EK1(order=3), pkg.EnsembleHIP(), trajectories=N, dt=2.0**-9, adaptive=True, max_steps=256)
+    else:
+        sol = pkg.solve(ens, pkg.EK1(order=3), pkg.EnsembleHIP(), trajectories=N, dt=2.0**-6, adaptive=False)
+    ds, times = sol.dense_sample_states(n, seed)
+    du, times2 = sol.dense_sample(n, seed)
+    assert ds.shape == (N, 1000, 12, n) and du.shape == (N, 1000, 3, n) and len(times) == 1000
+    assert times[0] == 0.0 and times[-1] == t1
+    np.testing.assert_array_equal(du, ds[:, :, :3, :])
+    tq = np.linspace(0.0, t1, 57)
+    st, _ = sol.dense_sample_states(n, seed, times=tq)
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    consts = orc.make_consts(3, 3)
+    for i in (0, 69):
+        if adaptive:
+            ref = orc.solve(vf, orc.EK1(order=3), u0=u0s[i], tspan=(0.0, t1), dt=2.0**-9, adaptive=True)
+        else:
+            ref = orc.solve(vf, orc.EK1(order=3), u0=u0s[i], tspan=(0.0, t1), dt=2.0**-6)
+        want, _ = orc.dense_sample_states(ref, consts, n, times=tq, sqrt="cholesky", seed=seed, traj=i)
+        scale = np.abs(want).max(axis=(0, 2))[None, :, None]
+        err = (np.abs(st[i] - want) / scale).max(axis=(0, 2))
+        assert err[:3].max() < (1e-6 if adaptive else 1e-8) and err.max() < 1e-3, err
+
+
 def test_sampling_needs_smoothing_solution(pkg):
     vf = orc.vector_field("lorenz63")
     prob = pkg.ODEProblem("lorenz63", vf.u0, (0.0, 0.1), vf.p)

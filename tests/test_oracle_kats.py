@@ -239,6 +239,20 @@ def test_sampling_shapes_and_outliers():
     assert out[1:].sum() < 0.05 * states[1:].size  # index 0 is the exact initial value (zero variance)
 
 
+def test_dense_sampling_shapes_and_grid_consistency():
+    """test/solution.jl:74-79, 98-103: shapes of dense_sample / dense_sample_states (1 000 times by default);
+    on the solver's own grid the dense sampler is the grid sampler (solution_sampling.jl:63-69 feeds the same
+    sample_states with filter-interpolated states, which at grid times are the filter states)."""
+    vf, sol, consts = _sampling_solution()
+    ds, times = orc.dense_sample_states(sol, consts, 3)
+    assert ds.shape == (1000, 8, 3) and len(times) == 1000
+    assert times[0] == sol.t[0] and times[-1] == sol.t[-1]
+    du, _ = orc.dense_sample(sol, consts, 3)
+    np.testing.assert_array_equal(du, ds[:, :2, :])
+    on_grid, _ = orc.dense_sample_states(sol, consts, 2, times=sol.t)
+    np.testing.assert_allclose(on_grid[1:], orc.sample_states(sol, consts, 2)[1:], rtol=1e-9, atol=1e-12)
+
+
 def test_sampling_zero_noise_is_the_smoothed_mean():
     """With the noise switched off the backward recursion of conditional means reproduces the RTS means."""
     vf, sol, consts = _sampling_solution()
