@@ -178,7 +178,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK, "traffic": traffic,
-                "kernel": "ek_filter_fixed_kernel<RhsLorenz63,3,true,%s>" % ("true" if everystep else "false"), "kernel_ms": k_ms,
+                "kernel": "odef::ek_filter_fixed_kernel<odef::RhsLorenz63, 3, true, %s, %s>" % (
+                    "true" if everystep else "false", "true" if (everystep and N < 32768) else "false"),  # name as rocprofv3 prints it
+                "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
             "parity_ok": ok,
