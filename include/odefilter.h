@@ -68,7 +68,8 @@ extern "C" {
 typedef struct odef_ctx odef_ctx;
 
 typedef enum { ODEF_EK0 = 0, ODEF_EK1 = 1 } odef_alg;
-typedef enum { ODEF_DIFFUSION_DYNAMIC = 0, ODEF_DIFFUSION_FIXED = 1 } odef_diffusion;
+/* diffusionmodel = :dynamic / :fixed / :fixedMAP (src/caches.jl:89-96, src/diffusions.jl:11-36, 46-68, 71-80) */
+typedef enum { ODEF_DIFFUSION_DYNAMIC = 0, ODEF_DIFFUSION_FIXED = 1, ODEF_DIFFUSION_FIXED_MAP = 2 } odef_diffusion;
 typedef enum {
   ODEF_RHS_FHN = 0,            /* u' = (c(u1 - u1^3/3 + u2), -(u1 - a - b u2)/c), p = (a,b,c) */
   ODEF_RHS_LORENZ63 = 1,       /* p = (sigma, rho, beta) */

@@ -221,13 +221,19 @@ __global__ void perturbed_u0_kernel(PerturbArgs a, double* __restrict__ dst /*[d
   }
 }
 
-__global__ void scale_cov_kernel(double* __restrict__ cov, const double* __restrict__ diff_last, double* __restrict__ diff,
-                                 double* __restrict__ loglik, long N, long n_save, int TRI) {
+__global__ void scale_cov_kernel(double* __restrict__ cov, double* __restrict__ diff, double* __restrict__ loglik,
+                                 const int* __restrict__ nsaved, long N, long n_save_fixed, int TRI) {
   // postamble! for static diffusion (src/integrator_utils.jl:4-18): Sigma *= final_diff, diffusions .= final_diff,
-  // sol.log_likelihood = NaN
+  // sol.log_likelihood = NaN.  nsaved != nullptr: adaptive solve, per-trajectory record count.
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const double s = diff_last[i];
+  const long n_save = nsaved ? (long)nsaved[i] : n_save_fixed;
+  const bool final_only = !nsaved && n_save_fixed == 1;  // final-save mode: slot 0 holds the last state and the last global diffusion
+  if (!final_only && n_save < 2) {  // no step taken: sol.diffusions is empty, nothing to rescale
+    loglik[i] = __builtin_nan("");
+    return;
+  }
+  const double s = diff[(size_t)(n_save - 1) * N + i];
   for (long n = 0; n < n_save; ++n) {
     for (int k = 0; k < TRI; ++k) cov[((size_t)n * TRI + k) * N + i] *= s;
     if (n >= 1) diff[(size_t)n * N + i] = s;
@@ -271,7 +277,7 @@ int odef_create(odef_ctx** out, const odef_config* cfg) {
   if (cfg->n_params != ri.np) return fail(nullptr, "odef_create: rhs %d has %d parameters, got %d", cfg->rhs_id, ri.np, cfg->n_params);
   if (cfg->order < 1 || cfg->order > ODEF_MAX_ORDER) return fail(nullptr, "odef_create: order %d outside 1..%d", cfg->order, ODEF_MAX_ORDER);
   if (cfg->alg != ODEF_EK0 && cfg->alg != ODEF_EK1) return fail(nullptr, "odef_create: unknown alg %d", cfg->alg);
-  if (cfg->diffusion != ODEF_DIFFUSION_DYNAMIC && cfg->diffusion != ODEF_DIFFUSION_FIXED)
+  if (cfg->diffusion != ODEF_DIFFUSION_DYNAMIC && cfg->diffusion != ODEF_DIFFUSION_FIXED && cfg->diffusion != ODEF_DIFFUSION_FIXED_MAP)
     return fail(nullptr, "odef_create: unknown diffusion model %d", cfg->diffusion);
   if (cfg->n_traj <= 0) return fail(nullptr, "odef_create: n_traj must be positive");
   if (cfg->rhs_id >= kJitFirstId && cfg->d * (cfg->order + 1) > 20)
@@ -424,7 +430,7 @@ static void fill_params(odef_ctx* c, FilterParams& P) {
   P.p_shared = c->cfg.params_shared;
   P.N = c->cfg.n_traj;
   P.everystep = c->cfg.save_mode == ODEF_SAVE_EVERYSTEP;
-  P.fixed_diffusion = c->cfg.diffusion == ODEF_DIFFUSION_FIXED;
+  P.fixed_diffusion = (int)c->cfg.diffusion;  // 0 dynamic, 1 fixed, 2 fixedMAP (static_diffusion_update, ek_math.h)
   P.want_loglik = c->cfg.want_loglik;
   {
     const char* e = getenv("ODEF_STAGGER");
@@ -445,12 +451,12 @@ static void fill_params(odef_ctx* c, FilterParams& P) {
 
 static int finish_filter(odef_ctx* c, int nlaunch) {
   // static diffusion: rescale all covariances by the final global diffusion (src/integrator_utils.jl:4-18)
-  if (c->cfg.diffusion == ODEF_DIFFUSION_FIXED && !c->adaptive) {
+  if (c->cfg.diffusion != ODEF_DIFFUSION_DYNAMIC) {
     const long N = c->cfg.n_traj;
-    double* diff = (double*)c->f[ODEF_F_DIFFUSION].ptr;
     hipLaunchKernelGGL(scale_cov_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, c->stream,
-                       (double*)c->f[ODEF_F_COV_TRIL].ptr, diff + (size_t)(c->n_save - 1) * N, diff,
-                       (double*)c->f[ODEF_F_LOGLIK].ptr, N, c->n_save, c->TRI);
+                       (double*)c->f[ODEF_F_COV_TRIL].ptr, (double*)c->f[ODEF_F_DIFFUSION].ptr,
+                       (double*)c->f[ODEF_F_LOGLIK].ptr, c->adaptive ? (const int*)c->f[ODEF_F_NSAVED].ptr : (const int*)nullptr,
+                       N, c->n_save, c->TRI);
     ++nlaunch;
   }
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));

@@ -179,15 +179,15 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigne
                               RowStore(P.mean + ((size_t)n * D * Nn + i0), Nn, D, lane),
                               RowStore(P.cov + ((size_t)n * TRI * Nn + i0), Nn, TRI, lane),
                               RowStore(P.diff + ((size_t)n * Nn + i0), Nn, 1, lane), 0};
-      S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux, sink);
+      S::run(P.pc, pl, tab, P.fixed_diffusion, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux, sink);
       sink.flush();
     } else if constexpr (EVERY) {
       RecordSink sink{RowStore(P.mean + ((size_t)(n + 1) * D * Nn + i0), Nn, D, lane),
                       RowStore(P.cov + ((size_t)(n + 1) * TRI * Nn + i0), Nn, TRI, lane)};
-      S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux, sink);
+      S::run(P.pc, pl, tab, P.fixed_diffusion, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux, sink);
     } else {
       NoSink nosink;
-      S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux, nosink);
+      S::run(P.pc, pl, tab, P.fixed_diffusion, P.want_loglik != 0, (int)n, gdiff, m, C, m2, C2, es, aux, nosink);
     }
 #pragma unroll
     for (int k = 0; k < D; ++k) m[k] = m2[k];
@@ -300,7 +300,7 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
     {
       double m2[D], C2[TRI];
       NoSink nosink;
-      S::run(P.pc, pl, tab, P.fixed_diffusion != 0, P.want_loglik != 0, naccept, gdiff, m, C, m2, C2, es, aux, nosink);
+      S::run(P.pc, pl, tab, P.fixed_diffusion, P.want_loglik != 0, naccept, gdiff, m, C, m2, C2, es, aux, nosink);
 #pragma unroll
       for (int k = 0; k < D; ++k) m[k] = m2[k];
 #pragma unroll

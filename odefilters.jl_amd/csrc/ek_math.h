@@ -248,6 +248,20 @@ __device__ inline void chol_small(const double (&S)[n][n], double (&L)[n][n], do
   }
 }
 
+// Global diffusion of the static models from this step's residual res_t = z' S^-1 z / d (`mode`: the C ABI's
+// odef_diffusion value).  1: FixedDiffusion, running mean (src/diffusions.jl:26-35).  2: MAPFixedDiffusion, mode of
+// the InverseGamma(1/2, 1/2) posterior rebuilt on-line from the previous estimate (src/diffusions.jl:46-68).
+template <int d>
+__host__ __device__ inline double static_diffusion_update(int mode, int success_iter, double prev, double res_t) {
+  if (mode != 2) return (success_iter == 0) ? res_t : prev + (res_t - prev) / success_iter;
+  const double alpha = 0.5, beta = 0.5;
+  const int n_obs = success_iter + 1;
+  if (success_iter == 0) return (beta + 0.5 * res_t) / (alpha + n_obs * d / 2.0 + 1.0);
+  const double res_prev = (prev * (alpha + (n_obs - 1) * d / 2.0 + 1.0) - beta) * 2.0;
+  const double res_sum_t = res_prev + res_t;
+  return (beta + 0.5 * res_sum_t) / (alpha + n_obs * d / 2.0 + 1.0);
+}
+
 template <class RHS, int q, bool IS_EK1>
 struct EKStep {
   static constexpr int d = RHS::d;
@@ -273,7 +287,7 @@ struct EKStep {
   // inside a run-time branch), so that a sink can spread its stores over the step (LaggedSink, ek_lane.h).
   template <class Sink>
   __device__ static inline void run(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab,
-                                    bool fixed_diffusion, bool want_loglik, int success_iter, double prev_global,
+                                    int fixed_diffusion, bool want_loglik, int success_iter, double prev_global,
                                     const double (&m)[D], const double (&C)[TRI], double (&m_out)[D],
                                     double (&C_out)[TRI], double (&err_scale)[d], StepAux& aux, Sink& sink) {
     // x~ = P x  (src/perform_step.jl:36-38)
@@ -467,10 +481,10 @@ struct EKStep {
     }
 
     if (fixed_diffusion) {
-      // FixedDiffusion (src/diffusions.jl:11-36): running mean of z' S^-1 z / d
+      // FixedDiffusion (src/diffusions.jl:11-36): running mean of z' S^-1 z / d;  MAPFixedDiffusion (:46-68)
       const double diffusion_t = zSz / d;
       aux.sigma2_local = diffusion_t;
-      aux.sigma2_global = (success_iter == 0) ? diffusion_t : prev_global + (diffusion_t - prev_global) / success_iter;
+      aux.sigma2_global = static_diffusion_update<d>(fixed_diffusion, success_iter, prev_global, diffusion_t);
     }
 
     // error estimate scale (src/perform_step.jl:148-158)

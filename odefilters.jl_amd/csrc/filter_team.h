@@ -55,7 +55,7 @@ struct TeamFilter {
 
   // One step (src/perform_step.jl:27-76).  ws->MV / X: current filter state, updated in place.
   __device__ static inline void step(const Team<TEAM>& t, const PriorConsts& pc, const double* __restrict__ p,
-                                     const double* __restrict__ tab, bool fixed_diffusion, int success_iter,
+                                     const double* __restrict__ tab, int fixed_diffusion, int success_iter,
                                      double* __restrict__ ws, double* __restrict__ sm) {
     double* X = ws + W::X;
     double* Y = ws + W::Y;
@@ -208,7 +208,7 @@ struct TeamFilter {
       if (fixed_diffusion) {  // src/diffusions.jl:11-36
         const double dt_ = zSz / d;
         sc[0] = dt_;
-        sc[4] = (success_iter == 0) ? dt_ : sc[4] + (dt_ - sc[4]) / success_iter;
+        sc[4] = static_diffusion_update<d>(fixed_diffusion, success_iter, sc[4], dt_);
       }
     }
     // rows of L1 times Q (src/filtering.jl:85-89): per reflector, one dot product per row, then a
@@ -284,7 +284,7 @@ struct TeamFilter {
     if (P.everystep) save(0);
     for (long n = 0; n < P.nsteps; ++n) {
       const double* tab = P.ptab + (size_t)P.tab_idx[n] * kTabStride;
-      step(t, P.pc, pl, tab, P.fixed_diffusion != 0, (int)n, ws, sm);
+      step(t, P.pc, pl, tab, P.fixed_diffusion, (int)n, ws, sm);
       if (P.everystep) save(n + 1);
     }
     if (!P.everystep) save(0);

@@ -112,7 +112,7 @@ struct TilesFilter {
 
   template <bool HELPER>
   ODEF_TILES_FN void step(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab,
-                                     bool fixed_diffusion, int success_iter, double* __restrict__ sm, TileState* st,
+                                     int fixed_diffusion, int success_iter, double* __restrict__ sm, TileState* st,
                                      int tid_dev) {
     (void)tid_dev;
     double* EX = sm + W::EX;
@@ -400,7 +400,7 @@ _Pragma("unroll")
         const double dt_ = zSz / d;
         const double prev = wv::load_uniform(wv::lds(sc + 4));
         wv::store_uniform(wv::lds(sc + 0), dt_);
-        wv::store_uniform(wv::lds(sc + 4), (success_iter == 0) ? dt_ : prev + (dt_ - prev) / success_iter);
+        wv::store_uniform(wv::lds(sc + 4), static_diffusion_update<d>(fixed_diffusion, success_iter, prev, dt_));
       }
     )
     ODEF_TILES_PHASE()  // the tile threads wait here for the helper
@@ -546,7 +546,7 @@ _Pragma("unroll")
     if (P.everystep) save_record<HELPER>(P, i, 0, 0.0, tid_dev, sm, st);
     for (long n = 0; n < P.nsteps; ++n) {
       const double* tab = P.ptab + (size_t)P.tab_idx[n] * kTabStride;
-      step<HELPER>(P.pc, pl, tab, P.fixed_diffusion != 0, (int)n, sm, st, tid_dev);
+      step<HELPER>(P.pc, pl, tab, P.fixed_diffusion, (int)n, sm, st, tid_dev);
       if (P.everystep) save_record<HELPER>(P, i, n + 1, sc[4], tid_dev, sm, st);
     }
     if (!P.everystep) save_record<HELPER>(P, i, 0, sc[4], tid_dev, sm, st);
@@ -616,7 +616,7 @@ _Pragma("unroll")
         }
       )
       if (ctl[0] == 0.0) break;  // workgroup-uniform
-      step<HELPER>(P.pc, pl, tabL, P.fixed_diffusion != 0, (int)ctl[3], sm, st, tid_dev);
+      step<HELPER>(P.pc, pl, tabL, P.fixed_diffusion, (int)ctl[3], sm, st, tid_dev);
       ODEF_TILES_PHASE(
         if (tid == 0) {
           // DiffEqBase.calculate_residuals! + ODE_DEFAULT_NORM (src/perform_step.jl:78-84); sc[0] = local diffusion

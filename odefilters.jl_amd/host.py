@@ -24,7 +24,7 @@ LIB_PATH = os.environ.get("ODEFILTER_HIP_LIB") or os.path.join(_HERE, "lib", "li
 
 # ---- enums (include/odefilter.h) ---------------------------------------------------------
 EK0_ID, EK1_ID = 0, 1
-DIFFUSION = {"dynamic": 0, "fixed": 1}
+DIFFUSION = {"dynamic": 0, "fixed": 1, "fixedMAP": 2}
 RHS = {"fhn": 0, "lorenz63": 1, "lotka_volterra": 2, "vanderpol": 3, "linear": 4, "pleiades": 5}
 RHS_DIMS = {"fhn": (2, 3), "lorenz63": (3, 3), "lotka_volterra": (2, 4), "vanderpol": (2, 1), "linear": (2, 2),
             "pleiades": (28, 0)}
@@ -610,7 +610,7 @@ def solve(prob, alg, ensemblealg: EnsembleHIP = EnsembleHIP(), *, trajectories: 
     if alg.prior != "ibm":
         raise OdefError("Only the ibm prior is implemented so far")  # src/caches.jl:69
     if alg.diffusionmodel not in DIFFUSION:
-        raise OdefError(f"diffusionmodel {alg.diffusionmodel!r} is not on the device path; use 'dynamic' or 'fixed'")
+        raise OdefError(f"diffusionmodel {alg.diffusionmodel!r} is not on the device path; use 'dynamic', 'fixed' or 'fixedMAP'")
     if not adaptive and dt is None and tstops is None:
         # test/errors.jl:17-19
         raise OdefError("Fixed timestep methods require a choice of dt or choosing the tstops")

@@ -491,7 +491,7 @@ class Alg:
 
     kind: str = "EK1"  # "EK0" | "EK1"
     order: int = 3
-    diffusionmodel: str = "dynamic"  # "dynamic" | "fixed"
+    diffusionmodel: str = "dynamic"  # "dynamic" | "fixed" | "fixedMAP"
     smooth: bool = True
 
 
@@ -577,7 +577,7 @@ def perform_step(alg: Alg, vf: VectorField, p, consts, x: SRGaussian, t: float, 
         L_pred, used_qr = predict_cov_sr(xp.L, A, apply_diffusion(Q_L, global_diffusion))
         HL = H @ L_pred
         S = HL @ HL.T
-    elif alg.diffusionmodel == "fixed":  # :56-63, diffusions.jl:11-36
+    elif alg.diffusionmodel in ("fixed", "fixedMAP"):  # :56-63, diffusions.jl:11-36 / :46-68
         m_pred = predict_mean(xp.mu, A)
         L_pred, used_qr = predict_cov_sr(xp.L, A, Q_L)
         z, H, _ = measure(alg, vf, p, m_pred, PI, tnew, d, q)
@@ -585,10 +585,20 @@ def perform_step(alg: Alg, vf: VectorField, p, consts, x: SRGaussian, t: float, 
         S = HL @ HL.T
         diffusion_t = float(z @ np.linalg.inv(S) @ z) / d
         local_diffusion = diffusion_t
-        if success_iter == 0:
-            global_diffusion = diffusion_t
-        else:
-            global_diffusion = prev_global_diffusion + (diffusion_t - prev_global_diffusion) / success_iter
+        if alg.diffusionmodel == "fixed":
+            if success_iter == 0:
+                global_diffusion = diffusion_t
+            else:
+                global_diffusion = prev_global_diffusion + (diffusion_t - prev_global_diffusion) / success_iter
+        else:  # MAPFixedDiffusion (diffusions.jl:46-68): mode of the InverseGamma(1/2, 1/2) posterior, on-line
+            n_obs = success_iter + 1
+            alpha, beta = 1 / 2, 1 / 2
+            if success_iter == 0:
+                global_diffusion = (beta + 1 / 2 * diffusion_t) / (alpha + n_obs * d / 2 + 1)
+            else:
+                res_prev = (prev_global_diffusion * (alpha + (n_obs - 1) * d / 2 + 1) - beta) * 2
+                res_sum_t = res_prev + diffusion_t
+                global_diffusion = (beta + 1 / 2 * res_sum_t) / (alpha + n_obs * d / 2 + 1)
     else:
         raise NotImplementedError(alg.diffusionmodel)
     x_pred = SRGaussian(m_pred, L_pred)
@@ -799,7 +809,7 @@ def solve(vf: VectorField, alg: Alg, *, u0=None, p=None, tspan=None, dt: Optiona
                 break
 
     # postamble! (integrator_utils.jl:2-30)
-    if alg.diffusionmodel == "fixed" and sol.diffusions:
+    if alg.diffusionmodel in ("fixed", "fixedMAP") and sol.diffusions:  # isstatic
         final = sol.diffusions[-1]
         sol.log_likelihood = float("nan")
         for s in sol.x_filt:

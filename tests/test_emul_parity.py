@@ -36,11 +36,13 @@ def test_fixed_step_filter_and_smoother(rhs, alg, dt, tspan):
     assert r["retcode"][0] == 0 and r["naccept"][0] == len(base.t) - 1
 
 
-def test_fixed_diffusion():
+@pytest.mark.parametrize("model", ["fixed", "fixedMAP"])
+def test_fixed_diffusion(model):
+    """FixedDiffusion / MAPFixedDiffusion (src/diffusions.jl:11-36, 46-68) in the lane step."""
     vf = orc.vector_field("lotka_volterra")
-    alg = orc.EK1(order=2, diffusionmodel="fixed", smooth=False)
+    alg = orc.EK1(order=2, diffusionmodel=model, smooth=False)
     sol = orc.solve(vf, alg, dt=5e-3, tspan=(0.0, 0.5))
-    r = E.emul_solve(vf.rhs_id, vf.d, 2, True, vf.u0[None, :], vf.p, tgrid=np.array(sol.t), fixed_diffusion=True)
+    r = E.emul_solve(vf.rhs_id, vf.d, 2, True, vf.u0[None, :], vf.p, tgrid=np.array(sol.t), fixed_diffusion={"fixed": 1, "fixedMAP": 2}[model])
     # the lane code returns unscaled covariances + the running-mean diffusion; the postamble rescale
     # (integrator_utils.jl:4-18) is a separate kernel in api.hip, re-done here
     final = r["diff"][0][-1]

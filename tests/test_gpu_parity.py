@@ -312,14 +312,39 @@ def test_pleiades_adaptive(pkg, kind, q):
         assert sol.t[i, n - 1] == t1
 
 
-def test_pleiades_fixed_diffusion(pkg):
-    """FixedDiffusion on the workgroup-per-trajectory path (tiled filter + helper wavefront, post-hoc covariance rescale,
-    team smoother): src/diffusions.jl:11-36, src/integrator_utils.jl:4-18."""
+@pytest.mark.parametrize("model", ["fixed", "fixedMAP"])
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_static_diffusion_models(pkg, model, adaptive):
+    """FixedDiffusion / MAPFixedDiffusion (src/diffusions.jl:11-36, 46-68; static order of src/perform_step.jl:56-63)
+    with the post-hoc calibration of postamble! (src/integrator_utils.jl:4-18), fixed grid and adaptive stepping (the
+    running estimate then only advances on accepted steps, and the rescale ends at each trajectory's own last record)."""
+    vf = orc.vector_field("lotka_volterra")
+    N, t1 = 70, 0.5
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("lotka_volterra", vf.u0, (0.0, t1), vf.p), perturb_scale=1e-2)
+    kw = dict(adaptive=True, dt=2.0**-8) if adaptive else dict(adaptive=False, dt=2.0**-6)
+    sol = pkg.solve(ens, pkg.EK1(order=3, diffusionmodel=model), pkg.EnsembleHIP(), trajectories=N, **kw)
+    assert sol.retcode == ["Success"] * N
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    for i in (0, 69):
+        ref = orc.solve(vf, orc.Alg("EK1", 3, model, True), u0=u0s[i], tspan=(0.0, t1), **kw)
+        n = len(ref.t)
+        assert int(sol.nsaved[i]) == n
+        np.testing.assert_allclose(sol.u[i, :n], ref.u, rtol=1e-6 if adaptive else 1e-10, atol=1e-12)
+        np.testing.assert_allclose(sol.diffusions[i, : n - 1], ref.diffusions, rtol=1e-5 if adaptive else 1e-8)
+        assert P.cov_err(sol.x_filt_cov()[i, :n], ref.covs(smoothed=False)) < (1e-4 if adaptive else 1e-6)
+        assert P.cov_err(sol.x_smooth_cov()[i, :n], ref.covs(smoothed=True)) < (1e-4 if adaptive else 1e-6)
+    assert np.isnan(sol.log_likelihood).all()  # src/integrator_utils.jl:7
+
+
+@pytest.mark.parametrize("model", ["fixed", "fixedMAP"])
+def test_pleiades_fixed_diffusion(pkg, model):
+    """FixedDiffusion / MAPFixedDiffusion on the workgroup-per-trajectory path (tiled filter + helper wavefront, post-hoc
+    covariance rescale, team smoother): src/diffusions.jl:11-36, 46-68, src/integrator_utils.jl:4-18."""
     vf = orc.vector_field("pleiades")
     ns, dt = 8, 2.0**-10
     prob = pkg.ODEProblem("pleiades", vf.u0, (0.0, ns * dt), ())
-    sol = pkg.solve(prob, pkg.EK1(order=2, diffusionmodel="fixed"), dt=dt, adaptive=False)
-    ref = orc.solve(vf, orc.Alg("EK1", 2, "fixed", True), dt=dt, tspan=(0.0, ns * dt))
+    sol = pkg.solve(prob, pkg.EK1(order=2, diffusionmodel=model), dt=dt, adaptive=False)
+    ref = orc.solve(vf, orc.Alg("EK1", 2, model, True), dt=dt, tspan=(0.0, ns * dt))
     np.testing.assert_allclose(sol.u[0], ref.u, rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(sol.diffusions[0], ref.diffusions, rtol=1e-8)
     assert P.cov_err(sol.x_filt_cov()[0], ref.covs(smoothed=False)) < 1e-6

@@ -155,6 +155,38 @@ def test_fixed_step_correctness(rhs, kind, diffusion, q):
     assert sol.retcode == "Success"
 
 
+@pytest.mark.parametrize("diffusion", ["dynamic", "fixed", "fixedMAP"])
+def test_diffusion_models(diffusion):
+    """test/diffusions.jl:8-36 (the scalar models; the MV ones are not built): EK0 on FitzHugh-Nagumo with a fixed
+    step reproduces the true solution whichever calibration is used -- the posterior MEAN of a fixed-step solve does
+    not depend on a static diffusion at all, so the two static models must give the same means to rounding.  (dt = 5e-3
+    instead of the reference's 1e-4 to keep the numpy loop short; tolerance as test/correctness.jl.)"""
+    vf = orc.vector_field("fhn")
+    sol = orc.solve(vf, orc.EK0(order=3, diffusionmodel=diffusion), dt=5e-3, tspan=(0.0, 2.0))
+    truth = _truth(vf, np.array(sol.t))
+    assert np.linalg.norm(sol.u - truth) <= 1e-5 * np.linalg.norm(truth)
+    if diffusion != "dynamic":
+        assert len(set(sol.diffusions)) == 1 and np.isnan(sol.log_likelihood)  # postamble! (integrator_utils.jl:4-18)
+        other = orc.solve(vf, orc.EK0(order=3, diffusionmodel="fixed"), dt=5e-3, tspan=(0.0, 2.0))
+        np.testing.assert_allclose(sol.means(), other.means(), rtol=1e-9, atol=1e-12)
+
+
+def test_map_diffusion_first_step_and_recursion():
+    """src/diffusions.jl:46-68 literally: first step (beta + res/2) / (alpha + d/2 + 1); later steps rebuild the
+    residual sum from the previous estimate.  Checked on the oracle's own per-step function."""
+    vf = orc.vector_field("lotka_volterra")
+    consts = orc.make_consts(2, 2)
+    x0 = orc.initial_update(vf.u0, vf, vf.p, 0.0, 2)
+    alg = orc.EK1(order=2, diffusionmodel="fixedMAP", smooth=False)
+    s1 = orc.perform_step(alg, vf, vf.p, consts, x0, 0.0, 2.0**-6, success_iter=0)
+    d = 2
+    np.testing.assert_allclose(s1.global_diffusion, (0.5 + 0.5 * s1.local_diffusion) / (0.5 + d / 2 + 1), rtol=1e-14)
+    s2 = orc.perform_step(alg, vf, vf.p, consts, s1.x_filt, 2.0**-6, 2.0**-6, success_iter=1,
+                          prev_global_diffusion=s1.global_diffusion)
+    want = (0.5 + 0.5 * (s1.local_diffusion + s2.local_diffusion)) / (0.5 + 2 * d / 2 + 1)  # mode of the posterior after 2 residuals
+    np.testing.assert_allclose(s2.global_diffusion, want, rtol=1e-12)
+
+
 @pytest.mark.parametrize("rhs", ["lotka_volterra", "fhn"])
 @pytest.mark.parametrize("q", [2, 4])
 def test_adaptive_correctness(rhs, q):
