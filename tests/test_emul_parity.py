@@ -254,3 +254,23 @@ def test_dense_posterior_sampling(adaptive):
     scale = np.abs(ref).max(axis=(0, 2))[None, :, None]
     err = (np.abs(S - ref) / scale).max(axis=(0, 2))
     assert err[:3].max() < 1e-8 and err.max() < 1e-4, err
+
+
+def test_dense_sampling_edge_grids():
+    """Degenerate dense grids: a single time (only the draw from the filter marginal), repeated times (h = 0: the
+    state is the later one, as for duplicated save times, src/smoothing.jl:13-16) and a grid equal to the solver's own
+    (then dense_sample_states is sample_states, both with the reference's square root replaced by the lower factor)."""
+    vf = orc.vector_field("lorenz63")
+    sol = orc.solve(vf, orc.EK1(order=3), dt=2.0**-6, tspan=(0.0, 0.25))
+    consts = orc.make_consts(3, 3)
+    kw = dict(tgrid=np.array(sol.t), smooth=True)
+    one = E.emul_solve(vf.rhs_id, 3, 3, True, vf.u0[None, :], vf.p, dense_sample=([0.1], 2, 3, 1.0), **kw)["dense_samples"][0]
+    ref, _ = orc.dense_sample_states(sol, consts, 2, times=[0.1], sqrt="cholesky", seed=3)
+    np.testing.assert_allclose(one[:, :3], ref[:, :3], rtol=1e-9)
+    tq = [0.05, 0.1, 0.1, 0.2]
+    dup = E.emul_solve(vf.rhs_id, 3, 3, True, vf.u0[None, :], vf.p, dense_sample=(tq, 2, 3, 1.0), **kw)["dense_samples"][0]
+    np.testing.assert_array_equal(dup[1], dup[2])
+    assert np.isfinite(dup).all()
+    grid = E.emul_solve(vf.rhs_id, 3, 3, True, vf.u0[None, :], vf.p, dense_sample=(sol.t, 2, 3, 1.0), sample=(2, 3, 1.0), **kw)
+    scale = np.abs(grid["samples"][0]).max(axis=(0, 2))[None, :, None]
+    assert (np.abs(grid["dense_samples"][0][1:] - grid["samples"][0][1:]) / scale).max() < 1e-9
