@@ -8,7 +8,7 @@ smooth of ProbNumDiffEq.jl) behind a C ABI.  Holds only what that path needs:
 from . import _build
 from .host import (  # noqa: F401
     EK0, EK1, Context, EnsembleHIP, EnsembleProblem, EnsembleSolution, ODEProblem, OdefController, OdefError,
-    compile_rhs, fixed_time_grid, ibm, load_library, preconditioner, predict, smooth_step, solve, unpack_tril, update,
+    compile_rhs, fixed_time_grid, ibm, load_library, preconditioner, predict, shard_ensemble, smooth_step, solve, unpack_tril, update,
 )
 
 build = _build.build

@@ -416,8 +416,32 @@ class EnsembleProblem:
 
 @dataclass(frozen=True)
 class EnsembleHIP:
-    """Ensemble algorithm: all trajectories on one MI355X (`device`), one lane per trajectory."""
+    """Ensemble algorithm: all trajectories on one MI355X (`device`), one lane per trajectory.
+
+    `distributed=True` (one process per GPU under torchrun): every rank solves the contiguous block of the trajectory
+    index `dist.shard_bounds` assigns to it on the GPU `LOCAL_RANK`, nothing is exchanged while stepping, and
+    `EnsembleSolution.gather_final()` is the single RCCL all-gather of the path."""
     device: int = -1
+    distributed: bool = False
+
+
+def shard_ensemble(prob: "EnsembleProblem", trajectories: Optional[int], rank: int, world: int):
+    """(per-rank EnsembleProblem, n_local, (lo, hi)): contiguous block of the trajectory index.  The synthetic ensemble
+    keeps its GLOBAL numbering (first_index + lo), explicit u0s / ps are sliced -- so the union of the shards is exactly
+    the ensemble one larger solve would produce."""
+    from . import dist as od
+
+    total = len(prob.u0s) if prob.u0s is not None else trajectories
+    if total is None:
+        raise OdefError("trajectories is required")
+    lo, hi = od.shard_bounds(int(total), rank, world)
+    if prob.u0s is not None:
+        local = EnsembleProblem(prob.prob, u0s=np.asarray(prob.u0s)[lo:hi], ps=None if prob.ps is None else np.asarray(prob.ps)[lo:hi])
+    else:
+        local = EnsembleProblem(prob.prob, ps=None if prob.ps is None else np.asarray(prob.ps)[lo:hi],
+                                perturb_scale=prob.perturb_scale, seed=prob.seed, first_index=prob.first_index + lo,
+                                n_perturbed=prob.n_perturbed)
+    return local, hi - lo, (lo, hi)
 
 
 def fixed_time_grid(t0: float, t1: float, dt: float) -> np.ndarray:
@@ -460,6 +484,35 @@ class EnsembleSolution:
         self.ctx, self.alg, self.adaptive = ctx, alg, adaptive
         self.d, self.q, self.D = ctx.d, ctx.q, ctx.D
         self._cache = {}
+        self.shard = None  # (lo, hi, total, world) of a distributed solve
+
+    def final_mean(self) -> np.ndarray:
+        """[N, D]: posterior mean of the state at each trajectory's last time (the filter state, which is also the
+        smoothed one there, src/smoothing.jl:11)."""
+        m = self._get(F_MEAN)  # [n_save, D, N]
+        if not self.adaptive:
+            return np.ascontiguousarray(m[-1].T)
+        last = self._get(F_NSAVED).astype(np.int64) - 1
+        return np.ascontiguousarray(m[last, :, np.arange(m.shape[2])])
+
+    def gather_final(self) -> np.ndarray:
+        """Distributed solves: the one collective of the path -- all-gather of the per-shard final means into
+        [N_total, D] in global trajectory order on every rank (RCCL over xGMI; shards may differ by one row, so they
+        are padded to the largest).  A non-distributed solve returns its own final means."""
+        mine = self.final_mean()
+        if self.shard is None or self.shard[3] == 1:
+            return mine
+        import torch
+
+        from . import dist as od
+
+        lo, hi, total, world = self.shard
+        rows = -(-total // world)
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
+        buf = torch.zeros((rows, self.D), dtype=torch.float64, device=dev)
+        buf[: hi - lo] = torch.from_numpy(mine).to(dev)
+        g = od.allgather_shards(buf, world).cpu().numpy()  # [world, rows, D]
+        return np.concatenate([g[r, : od.shard_bounds(total, r, world)[1] - od.shard_bounds(total, r, world)[0]] for r in range(world)])
 
     def _get(self, f):
         if f not in self._cache:
@@ -606,6 +659,18 @@ def solve(prob, alg, ensemblealg: EnsembleHIP = EnsembleHIP(), *, trajectories: 
     if isinstance(prob, ODEProblem):
         prob = EnsembleProblem(prob, u0s=np.asarray(prob.u0, float)[None, :])
         trajectories = 1
+    shard = None
+    if ensemblealg.distributed:
+        from . import dist as od
+
+        rank, world, local_rank = od.init_from_env(backend="nccl")
+        total = len(prob.u0s) if prob.u0s is not None else trajectories
+        prob, trajectories, (lo, hi) = shard_ensemble(prob, trajectories, rank, world)
+        if hi == lo:
+            raise OdefError(f"rank {rank} of {world} received no trajectory (ensemble of {total})")
+        shard = (lo, hi, int(total), world)
+        if ensemblealg.device < 0:
+            ensemblealg = EnsembleHIP(device=local_rank, distributed=True)
     base = prob.prob
     if alg.prior != "ibm":
         raise OdefError("Only the ibm prior is implemented so far")  # src/caches.jl:69
@@ -642,6 +707,7 @@ def solve(prob, alg, ensemblealg: EnsembleHIP = EnsembleHIP(), *, trajectories: 
         grid = np.asarray(tstops, float) if (tstops is not None and dt is None) else fixed_time_grid(t0, t1, dt)
         ctx.solve_fixed(grid)
     sol = EnsembleSolution(ctx, alg, adaptive)
+    sol.shard = shard
     if alg.smooth and ctx.cfg.save_mode == SAVE_EVERYSTEP:
         ctx.smooth()
     return sol

@@ -500,6 +500,28 @@ def test_dense_posterior_sampling(pkg, adaptive):
         assert err[:3].max() < (1e-6 if adaptive else 1e-8) and err.max() < 1e-3, err
 
 
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_distributed_solve_single_rank(pkg, adaptive, monkeypatch):
+    """EnsembleHIP(distributed=True) with one rank (the N > 1 exchange is covered by the gloo tests): the shard is the whole
+    ensemble, gather_final() is the final posterior mean of every trajectory (the last kept record of an adaptive solve)."""
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    vf = orc.vector_field("lorenz63")
+    N = 130
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, (0.0, 0.25), vf.p), perturb_scale=1e-2)
+    kw = dict(adaptive=True, dt=2.0**-9, max_steps=256) if adaptive else dict(adaptive=False, dt=2.0**-7)
+    sol = pkg.solve(ens, pkg.EK1(order=3), pkg.EnsembleHIP(distributed=True), trajectories=N, **kw)
+    assert sol.shard == (0, N, N, 1)
+    fin = sol.gather_final()
+    assert fin.shape == (N, 12)
+    xf = sol.x_filt_mean()
+    last = np.asarray(sol.nsaved) - 1 if adaptive else np.full(N, xf.shape[1] - 1)
+    np.testing.assert_array_equal(fin, xf[np.arange(N), last])
+    ref = orc.solve(vf, orc.EK1(order=3), u0=orc.ensemble_u0(vf.u0, N, 1e-2)[129], tspan=(0.0, 0.25),
+                    **(dict(adaptive=True, dt=2.0**-9) if adaptive else dict(dt=2.0**-7)))
+    np.testing.assert_allclose(fin[129, :3], ref.means(smoothed=False)[-1, :3], rtol=1e-6 if adaptive else 1e-10)
+
+
 def test_sampling_needs_smoothing_solution(pkg):
     vf = orc.vector_field("lorenz63")
     prob = pkg.ODEProblem("lorenz63", vf.u0, (0.0, 0.1), vf.p)
