@@ -4,9 +4,22 @@ int launch_filter_pleiades(int q, int ek1, const TeamFilterParams& TP, hipStream
   LaunchTeamFilter f{TP, s};
   return dispatch_order<RhsPleiades>(q, ek1, f);
 }
+// the tiled filter is instantiated one order per translation unit (inst_pleiades_tiles.hip with -DODEF_TILES_Q=q):
+// its kernels are the longest compiles of the library and used to serialise the build behind this file
+int launch_filter_pleiades_tiles_q1(int ek1, const FilterParams& P, hipStream_t s, int adaptive);
+int launch_filter_pleiades_tiles_q2(int ek1, const FilterParams& P, hipStream_t s, int adaptive);
+int launch_filter_pleiades_tiles_q3(int ek1, const FilterParams& P, hipStream_t s, int adaptive);
+int launch_filter_pleiades_tiles_q4(int ek1, const FilterParams& P, hipStream_t s, int adaptive);
+int launch_filter_pleiades_tiles_q5(int ek1, const FilterParams& P, hipStream_t s, int adaptive);
 int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive) {
-  LaunchTilesFilter f{P, s, adaptive};
-  return dispatch_order<RhsPleiades>(q, ek1, f);
+  switch (q) {
+    case 1: return launch_filter_pleiades_tiles_q1(ek1, P, s, adaptive);
+    case 2: return launch_filter_pleiades_tiles_q2(ek1, P, s, adaptive);
+    case 3: return launch_filter_pleiades_tiles_q3(ek1, P, s, adaptive);
+    case 4: return launch_filter_pleiades_tiles_q4(ek1, P, s, adaptive);
+    case 5: return launch_filter_pleiades_tiles_q5(ek1, P, s, adaptive);
+    default: return -2;
+  }
 }
 int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s) {
   LaunchTeamSmooth f{P, ws, s};
