@@ -12,6 +12,7 @@
 #include "sample_lane.h"
 #include "filter_team.h"
 #include "filter_tiles.h"
+#include "filter_rows.h"
 #include "launch.h"
 
 namespace odef {
@@ -29,6 +30,27 @@ __global__ __launch_bounds__(kWave) void ek_filter_fixed_kernel(const FilterPara
     for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
   }
   if (i0 + threadIdx.x < P.N) filter_fixed_lane<RHS, q, EK1, EVERY, LAG>(P, i0, threadIdx.x);
+}
+// Experimental small-ensemble mapping: row-per-lane teams (filter_rows.h), 16 lanes per trajectory, 4 trajectories per wavefront.
+// Workgroups go round-robin over the 8 XCDs; the block -> trajectory map gives each XCD one contiguous range of
+// trajectories, so that the 32-byte runs neighbouring wavefronts write into one cache line meet in the same L2.
+constexpr int kFilterRowsMaxD = 16;
+constexpr long kFilterRowsMaxN = 0;  // ensemble size below which the fixed-step filter uses the row-team kernel: OFF (measured no faster, filter_rows.h)
+inline long filter_rows_max_n() {
+  const char* e = getenv("ODEF_FILTER_ROWS_MAX_N");  // read at every launch, so tests can exercise both kernels
+  return e ? atol(e) : kFilterRowsMaxN;
+}
+template <class RHS, int q, bool EK1, bool EVERY>
+__global__ __launch_bounds__(kWave) void ek_filter_rows_kernel(const FilterParams P) {
+  constexpr int NB = q + 1, TEAM = kFilterRowsTeam, TPB = kWave / TEAM;
+  using W = FRowsWs<RHS::d, NB>;
+  __shared__ double lds[TPB * W::size];
+  const int team = threadIdx.x / TEAM, tid = threadIdx.x % TEAM;
+  const long per = (long)(gridDim.x / 8u);  // the grid is a multiple of 8 blocks
+  const long g = (long)(blockIdx.x % 8u) * per + (long)(blockIdx.x / 8u);
+  const long i = g * TPB + team;
+  FRow<RHS::d, NB> st;
+  if (i < P.N) filter_rows_lane<RHS, q, EK1, EVERY, TEAM>(P, i, tid, lds + team * W::size, &st);
 }
 template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kWave) void ek_filter_adaptive_kernel(const FilterParams P) {
@@ -204,6 +226,15 @@ struct LaunchFilter {
   template <class RHS, int q, bool EK1>
   void operator()() {
     const unsigned grid = (unsigned)((P.N + kWave - 1) / kWave);
+    if constexpr (RHS::d * (q + 1) <= kFilterRowsMaxD) {
+      if (!adaptive && P.N < filter_rows_max_n()) {  // small ensemble: 16 lanes per trajectory
+        constexpr long TPB = kWave / kFilterRowsTeam;
+        const unsigned rgrid = (unsigned)(((P.N + TPB - 1) / TPB + 7) / 8 * 8);
+        if (P.everystep) hipLaunchKernelGGL((ek_filter_rows_kernel<RHS, q, EK1, true>), dim3(rgrid), dim3(kWave), 0, s, P);
+        else hipLaunchKernelGGL((ek_filter_rows_kernel<RHS, q, EK1, false>), dim3(rgrid), dim3(kWave), 0, s, P);
+        return;
+      }
+    }
     if (adaptive) hipLaunchKernelGGL((ek_filter_adaptive_kernel<RHS, q, EK1>), dim3(grid), dim3(kWave), 0, s, P);
     else if (P.everystep && P.N < filter_lag_max_n())  // small ensemble: spread the record stores over the next step
       hipLaunchKernelGGL((ek_filter_fixed_kernel<RHS, q, EK1, true, true>), dim3(grid), dim3(kWave), 0, s, P);

@@ -20,8 +20,9 @@ _LIB = None
 def build():
     src = os.path.join(HERE, "emul", "emul.cpp")
     out = os.path.join(HERE, "emul", "libodef_emul.so")
-    deps = [src] + [os.path.join(ROOT, "odefilters.jl_amd", "csrc", f) for f in
-                    ("ek_math.h", "ek_lane.h", "rhs.h", "dispatch.h", "odef_platform.h", "team.h", "smooth_team.h", "filter_team.h", "smooth_rows.h", "smooth_lane.h", "dense_lane.h", "filter_tiles.h", "wave_vec.h", "sample_lane.h")]
+    import glob
+
+    deps = [src] + glob.glob(os.path.join(ROOT, "odefilters.jl_amd", "csrc", "*.h"))  # every device header
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O1", "-std=c++20", "-shared", "-fPIC", "-Wno-unknown-pragmas", src, "-o", out])
     return out
@@ -111,7 +112,7 @@ def emul_solve(rhs_id, d, q, ek1, u0s, p, *, team=False, tgrid=None, adaptive=Fa
         tg = np.ascontiguousarray(np.asarray(tgrid, float))
         hs = np.ascontiguousarray(np.diff(tg))
         nsteps = len(hs)
-        n_save = nsteps + 1 if everystep else 1
+        n_save = nsteps + 1 if int(everystep) > 0 else 1
         uniq, inv = np.unique(hs, return_inverse=True)
         stride = lib().emul_tab_stride()
         ptab = np.zeros((len(uniq), stride))

@@ -11,6 +11,7 @@
 #include "../../odefilters.jl_amd/csrc/filter_team.h"
 #include "../../odefilters.jl_amd/csrc/filter_tiles.h"
 #include "../../odefilters.jl_amd/csrc/sample_lane.h"
+#include "../../odefilters.jl_amd/csrc/filter_rows.h"
 #include <vector>
 #include <cstring>
 
@@ -45,8 +46,9 @@ static void fill(const EmulArgs& a, FilterParams& P) {
   P.t0 = a.t0; P.t1 = a.t1; P.abstol = a.abstol; P.reltol = a.reltol; P.dt0 = a.dt0;
   std::memcpy(&P.ctrl, a.ctrl, sizeof(Controller));
   P.max_save = a.max_save;
-  P.everystep = a.everystep != 0; P.fixed_diffusion = a.fixed_diffusion; P.want_loglik = a.want_loglik;
-  P.stagger = a.everystep == 2 ? 7 : 0;  // everystep == 2: the lagged record stores of the small-ensemble kernel
+  P.everystep = a.everystep > 0; P.fixed_diffusion = a.fixed_diffusion; P.want_loglik = a.want_loglik;
+  // everystep == 2: the lagged record stores of the small-ensemble kernel; 3 / -1: the row-team filter (every step / final)
+  P.stagger = a.everystep == 2 ? 7 : (a.everystep == 3 || a.everystep == -1) ? 9 : 0;
   P.mean = a.mean; P.cov = a.cov; P.diff = a.diff; P.tsave = a.tsave; P.loglik = a.loglik;
   P.naccept = a.naccept; P.nreject = a.nreject; P.nf = a.nf; P.njac = a.njac; P.nsaved = a.nsaved;
   P.retcode = a.retcode;
@@ -59,6 +61,15 @@ struct RunFilter {
   void operator()() {
     for (long i = 0; i < P.N; ++i) {
       const long i0 = (i / 64) * 64;
+      if (!adaptive && P.stagger == 9) {  // row-per-lane team filter (filter_rows.h): all lanes of a team, phase by phase
+        if constexpr (RHS::d * (q + 1) <= 16) {
+          std::vector<double> ws(FRowsWs<RHS::d, q + 1>::size);
+          std::vector<FRow<RHS::d, q + 1>> st(16);
+          if (P.everystep) filter_rows_lane<RHS, q, EK1, true, 16>(P, i, 0, ws.data(), st.data());
+          else filter_rows_lane<RHS, q, EK1, false, 16>(P, i, 0, ws.data(), st.data());
+        }
+        continue;
+      }
       if (adaptive) filter_adaptive_lane<RHS, q, EK1>(P, i0, (unsigned)(i - i0));
       else if (P.everystep && P.stagger == 7) filter_fixed_lane<RHS, q, EK1, true, true>(P, i0, (unsigned)(i - i0));  // lagged record stores
       else if (P.everystep) filter_fixed_lane<RHS, q, EK1, true>(P, i0, (unsigned)(i - i0));

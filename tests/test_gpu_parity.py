@@ -22,8 +22,16 @@ def _alg(pkg, kind, order, diffusion="dynamic", smooth=True):
 GOLDEN_FIXED = ["fhn_ek0_q1_cfg1", "lorenz_ek1_q3", "lv_ek1_q2_fixeddiff", "lv_ek0_q4", "vdp_ek1_q5"]
 
 
+# The fixed-step filter has a second, experimental mapping for D <= 16 (csrc/filter_rows.h, 16 lanes per trajectory; off by
+# default: it measured no faster than the lane filter); ODEF_FILTER_ROWS_MAX_N is read at every launch and
+# selects it for ensembles below that size.
+FILTER_KERNELS = {"lane": "0", "rows": "1000000000"}
+
+
+@pytest.mark.parametrize("kernel", ["lane", "rows"])
 @pytest.mark.parametrize("name", GOLDEN_FIXED)
-def test_golden_fixed_step(pkg, name):
+def test_golden_fixed_step(pkg, name, kernel, monkeypatch):
+    monkeypatch.setenv("ODEF_FILTER_ROWS_MAX_N", FILTER_KERNELS[kernel])
     g = np.load(os.path.join(GOLD, name + ".npz"))
     rhs, kind, order = str(g["rhs"]), str(g["kind"]), int(g["order"])
     diffusion = str(g["diffusionmodel"])
@@ -83,7 +91,9 @@ def test_golden_adaptive(pkg):
     ("vanderpol", "EK0", 3, 1e-2, 1.0),
     ("linear", "EK1", 2, 1e-2, 1.0),
 ])
-def test_ensemble_parity_with_oracle(pkg, rhs, kind, q, dt, t1):
+@pytest.mark.parametrize("kernel", ["lane", "rows"])
+def test_ensemble_parity_with_oracle(pkg, rhs, kind, q, dt, t1, kernel, monkeypatch):
+    monkeypatch.setenv("ODEF_FILTER_ROWS_MAX_N", FILTER_KERNELS[kernel])
     vf = orc.vector_field(rhs)
     N = 130  # ragged: not a multiple of the 64-lane wavefront
     ens = pkg.EnsembleProblem(pkg.ODEProblem(rhs, vf.u0, (0.0, t1), vf.p), perturb_scale=1e-2)
@@ -98,6 +108,35 @@ def test_ensemble_parity_with_oracle(pkg, rhs, kind, q, dt, t1):
             base, nm, nc = P.oracle_noise(vf, alg_o, u0s[i], dict(tspan=(0.0, t1), dt=dt), smoothed)
             P.check_against_oracle(m[i], c[i], base.means(smoothed=smoothed), base.covs(smoothed=smoothed), vf.d, nm, nc,
                                    f"{rhs} {kind}({q}) traj {i} smoothed={smoothed}")
+
+
+def test_row_team_filter_equals_lane_filter(pkg, monkeypatch):
+    """The two fixed-step filter kernels on the same ragged ensemble (every-step and final-only records, per-trajectory
+    parameters): results agree to rounding, counters and return codes are identical."""
+    vf = orc.vector_field("lorenz63")
+    N, t1, dt = 203, 0.5, 2.0**-8
+    rng = np.random.default_rng(5)
+    ps = np.asarray(vf.p)[None, :] * (1 + 1e-3 * rng.standard_normal((N, 3)))
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, (0.0, t1), vf.p), u0s=u0s, ps=ps)
+    out = {}
+    for kernel, v in FILTER_KERNELS.items():
+        monkeypatch.setenv("ODEF_FILTER_ROWS_MAX_N", v)
+        for every in (True, False):
+            sol = pkg.solve(ens, pkg.EK1(order=3, smooth=False), pkg.EnsembleHIP(), dt=dt, adaptive=False, save_everystep=every)
+            out[kernel, every] = (sol.x_filt_mean().copy(), sol.x_filt_cov().copy(), sol.log_likelihood.copy(),
+                                  sol.destats.nf.copy(), sol.destats.njacs.copy(), list(sol.retcode), np.asarray(sol.nsaved).copy())
+    for every in (True, False):
+        a, b = out["lane", every], out["rows", every]
+        scale = np.abs(a[0]).max(axis=(0, 1))
+        assert (np.abs(a[0] - b[0]).max(axis=(0, 1)) / scale)[:3].max() < 1e-11
+        assert (np.abs(a[0] - b[0]).max(axis=(0, 1)) / scale).max() < 1e-7  # derivative blocks (ill-conditioned, DESIGN 4)
+        assert P.cov_err(b[1], a[1]) < 1e-5
+        np.testing.assert_allclose(b[2], a[2], rtol=1e-8)
+        for k in (3, 4, 6):
+            np.testing.assert_array_equal(a[k], b[k])
+        assert a[5] == b[5] == ["Success"] * N
+    np.testing.assert_array_equal(out["rows", False][0][:, 0], out["rows", True][0][:, -1])  # final-only = last record
 
 
 @pytest.mark.parametrize("adaptive", [False, True])
