@@ -20,9 +20,10 @@ struct OdefConfig                      # odef_config, 56 bytes
 end
 
 const RHS_IDS = Dict(:fhn => 0, :lorenz63 => 1, :lotka_volterra => 2, :vanderpol => 3, :linear => 4)
-const DIFFUSIONS = Dict(:dynamic => 0, :fixed => 1)
+const DIFFUSIONS = Dict(:dynamic => 0, :fixed => 1, :fixedMAP => 2)   # src/caches.jl:89-96 (the MV models are not on the device)
 const F_MEAN, F_COV_TRIL, F_DIFFUSION, F_T, F_LOGLIK, F_NACCEPT, F_NREJECT, F_NF, F_NJAC, F_NSAVED,
       F_RETCODE, F_SMOOTH_MEAN, F_SMOOTH_COV_TRIL = 0:12
+const F_SAMPLES = 16
 const RETCODES = (:Success, :MaxIters, :DtLessThanMin, :Unstable, :Unstable)
 
 """Ensemble algorithm: all trajectories of an `EnsembleProblem` on one GPU, one lane per trajectory."""
@@ -68,7 +69,8 @@ view of the device layout [n_save][D][N]): `mean[i, k, s]`.
 """
 function DiffEqBase.__solve(eprob::DiffEqBase.EnsembleProblem, alg::Union{EK0,EK1}, ealg::EnsembleHIP;
                             trajectories::Int, u0s::Matrix{Float64}, dt=nothing, adaptive=true,
-                            abstol=1e-6, reltol=1e-3, max_steps=4096, kwargs...)
+                            abstol=1e-6, reltol=1e-3, max_steps=4096,
+                            nsamples::Int=0, sample_seed::UInt64=UInt64(0x5A3B1E), dense_sample_times=nothing, kwargs...)
     prob = eprob.prob
     d, N = size(u0s); @assert N == trajectories
     q = alg.order; D = d * (q + 1); TRI = D * (D + 1) ÷ 2
@@ -108,7 +110,17 @@ function DiffEqBase.__solve(eprob::DiffEqBase.EnsembleProblem, alg::Union{EK0,EK
                 keep[i, s] = s <= nsaved[i] && (s == 1 || tsave[i, s] != tsave[i, s - 1])
             end
         end
-        return (t = tsave, keep = keep,
+        # sample_states(sol, n) / dense_sample_states(sol, n) (src/solution_sampling.jl:15-75), while the context lives
+        samples = nothing; dense_samples = nothing
+        if nsamples > 0 && alg.smooth
+            check(ccall((:odef_sample, LIB), Cint, (Ptr{Cvoid}, Int64, UInt64, Cdouble), ctx, nsamples, sample_seed, 1.0), ctx)
+            samples = fetch(ctx, F_SAMPLES, Float64, N, nsamples, D, ns)
+            tq = dense_sample_times === nothing ? collect(range(t0, t1, length=1000)) : collect(Float64, dense_sample_times)
+            GC.@preserve tq check(ccall((:odef_dense_sample, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, UInt64, Cdouble),
+                                        ctx, tq, length(tq), nsamples, sample_seed, 1.0), ctx)
+            dense_samples = (fetch(ctx, F_SAMPLES, Float64, N, nsamples, D, length(tq)), tq)
+        end
+        return (t = tsave, keep = keep, samples = samples, dense_samples = dense_samples,
                 u = view(mean, :, 1:d, :), x_mean = mean, x_cov_tril = cov,
                 x_filt_mean = fetch(ctx, F_MEAN, Float64, N, D, ns),
                 diffusions = fetch(ctx, F_DIFFUSION, Float64, N, ns)[:, 2:end],
