@@ -54,6 +54,33 @@ struct StepAux {
   int chol_fix;          // number of non-positive pivots met by the Cholesky (QR-fallback cases)
 };
 
+// sqrt(x) and 1 / sqrt(x) together, for x > 0: v_rsq_f64 seed and two coupled Goldschmidt steps plus one residual correction each -- 14 instructions where a
+// correctly rounded sqrt followed by a correctly rounded division takes 28 (the pivots of the three factorisations of a
+// step are 12 such pairs, a tenth of its instructions).  Both results within an ulp (tools/rsqrt_accuracy.hip).
+__device__ inline void sqrt_and_rsqrt(double x, double& s, double& rs) {
+#ifdef ODEF_HOST_EMUL
+  s = sqrt(x);
+  rs = 1.0 / s;
+#else
+  const double y0 = __builtin_amdgcn_rsq(x);
+  double g = x * y0;
+  double h = 0.5 * y0;
+  double r = __builtin_fma(-g, h, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  r = __builtin_fma(-g, h, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double dd = __builtin_fma(-g, g, x);  // residual correction of the root
+  g = __builtin_fma(dd, h, g);
+  double y = h + h;
+  const double e = __builtin_fma(-g, y, 1.0);  // and of its reciprocal
+  y = __builtin_fma(e, y, y);
+  s = g;
+  rs = y;
+#endif
+}
+
 // In-place Cholesky of a packed symmetric matrix (lower).  A non-positive pivot means the
 // reference's `cholesky!(check=false)` would report failure and fall back to a QR
 // (src/filtering.jl:38-47); for a positive *semi*-definite matrix the equivalent factor is
@@ -234,9 +261,9 @@ __device__ inline void chol_small(const double (&S)[n][n], double (&L)[n][n], do
     double s = S[j][j];
 #pragma unroll
     for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
-    const double ljj = sqrt(s);
+    double ljj, inv;
+    sqrt_and_rsqrt(s, ljj, inv);
     L[j][j] = ljj;
-    const double inv = 1.0 / ljj;
     Ldinv[j] = inv;
 #pragma unroll
     for (int i = j + 1; i < n; ++i) {
@@ -396,8 +423,10 @@ struct EKStep {
       sink.tick();
       const double piv = X[tri(k, k)];
       const bool ok = piv > 0.0;  // a failing pivot is the reference's QR-fallback case (src/filtering.jl:38-47)
-      const double lkk = ok ? sqrt(piv) : 0.0;
-      const double inv = ok ? 1.0 / lkk : 0.0;
+      double root, rroot;
+      sqrt_and_rsqrt(piv, root, rroot);
+      const double lkk = ok ? root : 0.0;
+      const double inv = ok ? rroot : 0.0;
       aux.chol_fix += ok ? 0 : 1;
       X[tri(k, k)] = lkk;
 #pragma unroll
@@ -428,16 +457,18 @@ struct EKStep {
       }
     }
     // Householder QR of G: G = Q [R; 0];  S = G'G = R'R  (measurement covariance, src/perform_step.jl:54)
-    double hv[d][d2], hbeta[d], R[d][d];
+    double hv[d][d2], hbeta[d], R[d][d], Rdinv[d];
 #pragma unroll
     for (int k = 0; k < d; ++k) {
       sink.tick();
       double nrm2 = 0.0;
 #pragma unroll
       for (int i = k; i < d2; ++i) nrm2 += G[i][k] * G[i][k];
-      const double nrm = sqrt(nrm2);
+      double nrm, rnrm;
+      sqrt_and_rsqrt(nrm2, nrm, rnrm);
       const double x0 = G[k][k];
       const double alpha = (x0 >= 0.0) ? -nrm : nrm;
+      Rdinv[k] = (x0 >= 0.0) ? -rnrm : rnrm;  // 1 / R[k][k]
       const double v0 = x0 - alpha;
       const double vtv = nrm2 - x0 * x0 + v0 * v0;
       const double beta = (vtv > 0.0) ? 2.0 / vtv : 0.0;
@@ -467,7 +498,7 @@ struct EKStep {
       double t = z[r];
 #pragma unroll
       for (int c = 0; c < r; ++c) t -= R[c][r] * y[c];
-      y[r] = t / R[r][r];
+      y[r] = t * Rdinv[r];
       zSz += y[r] * y[r];
       if constexpr (d <= 4) detprod *= R[r][r];
       else if (want_loglik) logacc += log(fabs(R[r][r]));
