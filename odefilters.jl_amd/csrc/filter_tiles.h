@@ -290,8 +290,11 @@ _Pragma("unroll")
             constexpr int kc = decltype(kcc)::value;
             const double piv = S.x[kc][kc];
             const bool ok = piv > 0.0;
-            const double dg = ok ? sqrt(piv) : 0.0;
-            const double rs = ok ? 1.0 / dg : 0.0;
+            double root;
+            double rroot;
+            sqrt_and_rsqrt(piv, root, rroot);  // 56 dependent pivots per step sit on the workgroup's critical path
+            const double dg = ok ? root : 0.0;
+            const double rs = ok ? rroot : 0.0;
             invd[kc] = rs;
             S.x[kc][kc] = dg;
 _Pragma("unroll")
