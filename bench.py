@@ -64,8 +64,8 @@ def cpu_baseline(seconds_budget=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)  # the first launches after allocation run 5-8 % slower (first touch of 48.9 GB, clock ramp)
     ap.add_argument("--traj", type=int, default=65536, help="trajectories per GPU (weak scaling, the default)")
     ap.add_argument("--total-traj", type=int, default=0,
                     help="strong scaling instead: this many trajectories in total, split evenly over the ranks")
