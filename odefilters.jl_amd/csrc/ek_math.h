@@ -85,14 +85,19 @@ __device__ inline void sqrt_and_rsqrt(double x, double& s, double& rs) {
 // reference's `cholesky!(check=false)` would report failure and fall back to a QR
 // (src/filtering.jl:38-47); for a positive *semi*-definite matrix the equivalent factor is
 // obtained by zeroing that column, which is what is done here (counted in `fixes`).
+// `dinv` receives the reciprocals of the diagonal (0 for a zeroed column): the smoother's two triangular transforms
+// would otherwise divide by every pivot twice more.
 template <int D>
-__device__ inline void chol_packed(double (&B)[D * (D + 1) / 2], int& fixes) {
+__device__ inline void chol_packed(double (&B)[D * (D + 1) / 2], int& fixes, double (&dinv)[D]) {
 #pragma unroll
   for (int k = 0; k < D; ++k) {
     double piv = B[tri(k, k)];
     const bool ok = piv > 0.0;
-    const double lkk = ok ? sqrt(piv) : 0.0;
-    const double inv = ok ? 1.0 / lkk : 0.0;
+    double root, rroot;
+    sqrt_and_rsqrt(piv, root, rroot);
+    const double lkk = ok ? root : 0.0;
+    const double inv = ok ? rroot : 0.0;
+    dinv[k] = inv;
     fixes += ok ? 0 : 1;
     B[tri(k, k)] = lkk;
 #pragma unroll
@@ -104,6 +109,11 @@ __device__ inline void chol_packed(double (&B)[D * (D + 1) / 2], int& fixes) {
       for (int i = j; i < D; ++i) B[tri(i, j)] -= B[tri(i, k)] * ljk;
     }
   }
+}
+template <int D>
+__device__ inline void chol_packed(double (&B)[D * (D + 1) / 2], int& fixes) {
+  double dinv[D];
+  chol_packed<D>(B, fixes, dinv);
 }
 
 // Cholesky-based inverse of a small SPD matrix; returns log(det) = 2*sum(log L_ii) if asked.

@@ -24,12 +24,11 @@ struct LaneMem {
 
 // S <- L^-1 S L^-T  then  S <- L^-T S L^-1   (packed lower symmetric S, packed lower Cholesky factor L)
 template <int D>
-__device__ inline void two_sided_inverse(double (&S)[D * (D + 1) / 2], const double (&L)[D * (D + 1) / 2]) {
+__device__ inline void two_sided_inverse(double (&S)[D * (D + 1) / 2], const double (&L)[D * (D + 1) / 2], const double (&dinv)[D]) {
   // forward: elementary congruences with L_k^-1
   static_for<0, D>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    const double lkk = L[tri(k, k)];
-    const double inv = (lkk != 0.0) ? 1.0 / lkk : 0.0;
+    const double inv = dinv[k];  // 1 / L_kk from the factorisation (0 for a zeroed column)
     const double tkk = S[tri(k, k)] * inv * inv;
     S[tri(k, k)] = tkk;
 #pragma unroll
@@ -55,8 +54,7 @@ __device__ inline void two_sided_inverse(double (&S)[D * (D + 1) / 2], const dou
   // backward: elementary congruences with L_k^-T (only row/column k changes)
   static_for<0, D>([&](auto kc) {
     constexpr int k = D - 1 - decltype(kc)::value;
-    const double lkk = L[tri(k, k)];
-    const double inv = (lkk != 0.0) ? 1.0 / lkk : 0.0;
+    const double inv = dinv[k];  // 1 / L_kk from the factorisation (0 for a zeroed column)
     double t[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -143,7 +141,8 @@ __device__ inline void rts_step_core(const PriorConsts& pc, const double (&pij)[
 #pragma unroll
   for (int k = 0; k < TRI; ++k) Cs[k] -= B[k];  // M = S^s_+ - S^-
   int fixes = 0;
-  chol_packed<D>(B, fixes);
+  double dinv[D];  // 1 / L_kk (0 for a zeroed column): every later division by a pivot is a multiplication with these
+  chol_packed<D>(B, fixes, dinv);
   ODEF_SCHED_FENCE();
   // w = A' B^-1 delta ;  m^s = m + X w  (src/smoothing.jl:42-44)
 #pragma unroll
@@ -151,14 +150,14 @@ __device__ inline void rts_step_core(const PriorConsts& pc, const double (&pij)[
     double t = dl[k];
 #pragma unroll
     for (int c = 0; c < k; ++c) t -= B[tri(k, c)] * dl[c];
-    dl[k] = (B[tri(k, k)] != 0.0) ? t / B[tri(k, k)] : 0.0;
+    dl[k] = t * dinv[k];
   }
 #pragma unroll
   for (int k = D - 1; k >= 0; --k) {
     double t = dl[k];
 #pragma unroll
     for (int c = k + 1; c < D; ++c) t -= B[tri(c, k)] * dl[c];
-    dl[k] = (B[tri(k, k)] != 0.0) ? t / B[tri(k, k)] : 0.0;
+    dl[k] = t * dinv[k];
   }
   double wv[D];
 #pragma unroll
@@ -172,7 +171,7 @@ __device__ inline void rts_step_core(const PriorConsts& pc, const double (&pij)[
     }
   // Z = B^-1 M B^-1 ;  W = A' Z A
   ODEF_SCHED_FENCE();
-  two_sided_inverse<D>(Cs, B);
+  two_sided_inverse<D>(Cs, B, dinv);
   ODEF_SCHED_FENCE();
   congruence_At_inplace<d, NB>(pc, Cs);
   ODEF_SCHED_FENCE();
