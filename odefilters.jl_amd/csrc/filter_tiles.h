@@ -2,7 +2,7 @@
 // trajectory, 320 tile threads + one helper wavefront, with the packed covariance DISTRIBUTED IN REGISTERS: tile
 // thread t owns one 7 x 7 tile of the lower triangle (24 x 25 / 2 = 300 tiles at D = 168) for the whole solve; LDS
 // (<= 160 KB) is only the exchange medium.  Same arithmetic as EKStep::run (ek_math.h):
-//   congruence  A S A'                every thread gathers the <= 36 source tiles of its tile from LDS
+//   congruence  A S A'                two stages through LDS, Y = S A' then A Y: <= 2 NB source tiles per thread
 //   chol(H Q H'), sigma2              helper wavefront, in registers, concurrent with the congruence (wave_vec.h)
 //   partial Cholesky (first 2d cols)  blocked: diagonal tile factored in registers, panel tiles solved, trailing
 //                                     tiles updated with two panel tiles read from LDS
@@ -219,24 +219,26 @@ struct TilesFilter {
       )
     }
     ODEF_STAMP(4)
-    // predict_cov! (src/filtering.jl:33-41): own tile of A S A' from the published tiles (sigma2 Q is added below)
+    // predict_cov! (src/filtering.jl:33-41): own tile of A S A' (sigma2 Q is added below), in TWO stages through the
+    // tile exchange: Y = S A' (own tile: <= NB source tiles of the own tile ROW), then A Y (<= NB tiles of the own tile
+    // COLUMN, all of them below the diagonal: row tile j*tpb+si >= I >= J).  The slowest thread gathers 2 NB tiles
+    // instead of NB^2 (12 instead of 36 at order 5) -- the phases last as long as their slowest thread.
     ODEF_TILES_PHASE(
       if (S.I >= 0) {
         const int Jb = S.I / tpb;
-        const int si = S.I % tpb;
         const int Kb = S.J / tpb;
         const int sj = S.J % tpb;
+        const int rt = S.I;
         double acc[TS][TS];
 _Pragma("unroll")
         for (int r = 0; r < TS; ++r)
 _Pragma("unroll")
           for (int c = 0; c < TS; ++c) acc[r][c] = 0.0;
-        static_for<0, NB * NB>([&](auto jk) {  // compile-time (j, k): the coefficient rows stay in registers
+        static_for<0, NB * NB>([&](auto jk) {  // compile-time (j, k): j = own block row, k = source block column
           constexpr int j = decltype(jk)::value / NB;
           constexpr int k = decltype(jk)::value % NB;
-          if (j >= Jb && k >= Kb) {
-            const double coef = S.aj[j] * S.ak[k];
-            const int rt = j * tpb + si;
+          if (j == Jb && k >= Kb) {
+            const double coef = S.ak[k];
             const int ct = k * tpb + sj;
             // The source tile is stored as (rt, ct) when rt >= ct and transposed as (ct, rt) otherwise.  The two
             // cases are separate code paths so that every LDS read is base + compile-time offset.
@@ -261,6 +263,45 @@ _Pragma("unroll")
                 gather(std::true_type{});
               else
                 gather(std::false_type{});
+            }
+          }
+        });
+_Pragma("unroll")
+        for (int r = 0; r < TS; ++r)
+_Pragma("unroll")
+          for (int c = 0; c < TS; ++c) S.x[r][c] = acc[r][c];
+      }
+    )
+    ODEF_TILES_PHASE(  // every S tile has been read: the exchange now carries Y
+      if (S.I >= 0) {
+_Pragma("unroll")
+        for (int r = 0; r < TS; ++r)
+_Pragma("unroll")
+          for (int c = 0; c < TS; ++c) EX[S.tile * T2 + r * TS + c] = S.x[r][c];
+      }
+    )
+    ODEF_TILES_PHASE(
+      if (S.I >= 0) {
+        const int Jb = S.I / tpb;
+        const int si = S.I % tpb;
+        double acc[TS][TS];
+_Pragma("unroll")
+        for (int r = 0; r < TS; ++r)
+_Pragma("unroll")
+          for (int c = 0; c < TS; ++c) acc[r][c] = 0.0;
+        static_for<0, NB>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if (j >= Jb) {
+            const double coef = S.aj[j];
+            const int rt = j * tpb + si;
+            const double* src = EX + (rt * (rt + 1) / 2 + S.J) * T2;
+_Pragma("unroll")
+            for (int r = 0; r < TS; ++r) {
+              double v[TS];
+_Pragma("unroll")
+              for (int c = 0; c < TS; ++c) v[c] = src[r * TS + c];
+_Pragma("unroll")
+              for (int c = 0; c < TS; ++c) acc[r][c] += coef * v[c];
             }
           }
         });
