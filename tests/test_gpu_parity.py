@@ -262,6 +262,37 @@ def test_full_size_properties(pkg):
     np.testing.assert_array_equal(sol3.ctx.get(1)[0], cov[-1])
 
 
+def test_repeated_solves_reuse_and_replace_the_grid_tables(pkg):
+    """odef_solve_fixed keeps the preconditioner tables of the last grid on the device and skips the uploads when the
+    same grid comes again; a different grid (same length, other steps), an adaptive solve in between, and the first grid
+    again must each give exactly what a fresh context gives."""
+    vf = orc.vector_field("lorenz63")
+    N = 70
+    grid_a = np.arange(33) * 2.0**-8
+    grid_b = np.cumsum(np.concatenate([[0.0], np.tile([2.0**-9, 2.0**-8], 16)]))  # same length, alternating steps
+
+    def fresh(grid):
+        c = pkg.Context("lorenz63", 3, 1, N, smooth=False)
+        c.set_problem_perturbed(list(vf.u0), list(vf.p), 0.0, 1e-2)
+        c.solve_fixed(grid)
+        out = (c.get(0).copy(), c.get(1).copy(), c.get(2).copy())
+        c.close()
+        return out
+
+    want_a, want_b = fresh(grid_a), fresh(grid_b)
+    c = pkg.Context("lorenz63", 3, 1, N, smooth=False)
+    c.set_problem_perturbed(list(vf.u0), list(vf.p), 0.0, 1e-2)
+    for grid, want in ((grid_a, want_a), (grid_a, want_a), (grid_b, want_b), (grid_a, want_a)):
+        c.solve_fixed(grid)
+        for f in range(3):
+            np.testing.assert_array_equal(c.get(f), want[f])
+    c.solve_adaptive(float(grid_a[-1]), 1e-6, 1e-3, 2.0**-9, None, 64)
+    c.solve_fixed(grid_a)
+    for f in range(3):
+        np.testing.assert_array_equal(c.get(f), want_a[f])
+    c.close()
+
+
 def test_caller_owned_output_buffers_and_stream(pkg):
     """odef_bind_device / odef_set_stream with torch-owned memory and torch's stream."""
     import torch
