@@ -534,33 +534,58 @@ struct EKStep {
     for (int r = 0; r < d; ++r) err_scale[r] = sqrt(aux.sigma2_local * W[r][r]);
     sink.tick();
 
-    // update! (src/filtering.jl:79-91): rows of L1 times Q
+    // update! (src/filtering.jl:79-91): rows of L1 times Q, Q = H_1 ... H_d.  Only d + 1 combinations of the columns of Q
+    // are needed -- Q [y; 0] for the mean (K z = (L1 Q)[:, :d] y) and Q e_{d+r} for Z = (L1 Q)[:, d:2d] -- so the
+    // reflectors are applied to those d + 1 vectors once instead of to every one of the D rows of L1.
+    double qy[d2], qz[d][d2];
+#pragma unroll
+    for (int c = 0; c < d2; ++c) qy[c] = (c < d) ? y[c < d ? c : 0] : 0.0;
+#pragma unroll
+    for (int r = 0; r < d; ++r)
+#pragma unroll
+      for (int c = 0; c < d2; ++c) qz[r][c] = (c == d + r) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = d - 1; k >= 0; --k) {  // Q x = H_1 (H_2 (... H_d x))
+      sink.tick();
+      {
+        double s = 0.0;
+#pragma unroll
+        for (int c = k; c < d2; ++c) s += hv[k][c] * qy[c];
+        s *= hbeta[k];
+#pragma unroll
+        for (int c = k; c < d2; ++c) qy[c] -= s * hv[k][c];
+      }
+#pragma unroll
+      for (int r = 0; r < d; ++r) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = k; c < d2; ++c) s += hv[k][c] * qz[r][c];
+        s *= hbeta[k];
+#pragma unroll
+        for (int c = k; c < d2; ++c) qz[r][c] -= s * hv[k][c];
+      }
+    }
     double Zp[D][d];
 #pragma unroll
     for (int l = 0; l < D; ++l) {
       sink.tick();
-      double w[d2];
-#pragma unroll
-      for (int c = 0; c < d2; ++c) w[c] = (c <= l) ? X[tri(l, c)] : 0.0;
-#pragma unroll
-      for (int k = 0; k < d; ++k) {
-        if (k % 2 == 1) sink.tick();
-        double s = 0.0;
-#pragma unroll
-        for (int c = k; c < d2; ++c) s += w[c] * hv[k][c];
-        s *= hbeta[k];
-#pragma unroll
-        for (int c = k; c < d2; ++c) w[c] -= s * hv[k][c];
-      }
-      // m = m_p + K (0 - z),  K z = (L1 Q)[:, :d] y
+      // m = m_p + K (0 - z)
       double t = mp[l];
 #pragma unroll
-      for (int r = 0; r < d; ++r) t -= w[r] * y[r];
+      for (int c = 0; c < d2; ++c)
+        if (c <= l) t -= X[tri(l, c)] * qy[c];
       m_out[l] = tab[kTabPIJ + l / d] * t;  // un-precondition (src/perform_step.jl:75)
       sink.mean(m_out[l]);
       sink.tick();
 #pragma unroll
-      for (int r = 0; r < d; ++r) Zp[l][r] = w[d + r];
+      for (int r = 0; r < d; ++r) {
+        double z2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < d2; ++c)
+          if (c <= l) z2 += X[tri(l, c)] * qz[r][c];
+        Zp[l][r] = z2;
+      }
+      sink.tick();
     }
     // Sigma_filt = Zp Zp' + Schur, then un-precondition (src/perform_step.jl:73-75)
 #pragma unroll
