@@ -12,7 +12,7 @@
 #include "sample_lane.h"
 #include "filter_team.h"
 #include "filter_tiles.h"
-#include "filter_rows.h"
+#include "rows_filter.h"
 #include "launch.h"
 
 namespace odef {
@@ -31,26 +31,40 @@ __global__ __launch_bounds__(kWave) void ek_filter_fixed_kernel(const FilterPara
   }
   if (i0 + threadIdx.x < P.N) filter_fixed_lane<RHS, q, EK1, EVERY, LAG>(P, i0, threadIdx.x);
 }
-// Experimental small-ensemble mapping: row-per-lane teams (filter_rows.h), 16 lanes per trajectory, 4 trajectories per wavefront.
+// Small / sharded ensembles: 16 lanes per trajectory (rows_filter.h), 4 trajectories per wavefront.
 // Workgroups go round-robin over the 8 XCDs; the block -> trajectory map gives each XCD one contiguous range of
 // trajectories, so that the 32-byte runs neighbouring wavefronts write into one cache line meet in the same L2.
-constexpr int kFilterRowsMaxD = 16;
-constexpr long kFilterRowsMaxN = 0;  // ensemble size below which the fixed-step filter uses the row-team kernel: OFF (measured no faster, filter_rows.h)
+constexpr int kRowsMaxD = tv::kTeam;
+// Ensemble size below which the filter uses the row-team kernels.  Cost model from tools/dpp_bench.hip: a wavefront
+// alone on its SIMD issues one instruction per ~3 ns whatever it is, so the lane kernel needs ~5 us per step at any
+// N <= 65 536 and the row-team kernel (I instructions per wave-step, N / 4 waves) I x 3 ns x max(1, N / 4096);
+// measured crossover: profiles/r02_rows_vs_lane.jsonl.  ODEF_FILTER_ROWS_MAX_N overrides it (read at every launch,
+// so tests can exercise both kernels).
+constexpr long kFilterRowsMaxN = 24576;
 inline long filter_rows_max_n() {
-  const char* e = getenv("ODEF_FILTER_ROWS_MAX_N");  // read at every launch, so tests can exercise both kernels
+  const char* e = getenv("ODEF_FILTER_ROWS_MAX_N");
   return e ? atol(e) : kFilterRowsMaxN;
+}
+__device__ inline long rows_team_trajectory(unsigned block, unsigned nblocks, int team) {
+  const long per = (long)(nblocks / 8u);  // the grid is a multiple of 8 blocks
+  const long g = (long)(block % 8u) * per + (long)(block / 8u);
+  return g * (kWave / tv::kTeam) + team;
 }
 template <class RHS, int q, bool EK1, bool EVERY>
 __global__ __launch_bounds__(kWave) void ek_filter_rows_kernel(const FilterParams P) {
-  constexpr int NB = q + 1, TEAM = kFilterRowsTeam, TPB = kWave / TEAM;
-  using W = FRowsWs<RHS::d, NB>;
-  __shared__ double lds[TPB * W::size];
-  const int team = threadIdx.x / TEAM, tid = threadIdx.x % TEAM;
-  const long per = (long)(gridDim.x / 8u);  // the grid is a multiple of 8 blocks
-  const long g = (long)(blockIdx.x % 8u) * per + (long)(blockIdx.x / 8u);
-  const long i = g * TPB + team;
-  FRow<RHS::d, NB> st;
-  if (i < P.N) filter_rows_lane<RHS, q, EK1, EVERY, TEAM>(P, i, tid, lds + team * W::size, &st);
+  constexpr int TPB = kWave / tv::kTeam, LDSZ = tv::kLdsRows * tv::lds_ld(RHS::d * (q + 1));
+  __shared__ __attribute__((aligned(16))) double lds[TPB * LDSZ];
+  const int team = threadIdx.x / tv::kTeam;
+  const long i = rows_team_trajectory(blockIdx.x, gridDim.x, team);
+  if (i < P.N) rows_filter_fixed<RHS, q, EK1, EVERY>(P, i, lds + team * LDSZ);
+}
+template <class RHS, int q, bool EK1>
+__global__ __launch_bounds__(kWave) void ek_filter_rows_adaptive_kernel(const FilterParams P) {
+  constexpr int TPB = kWave / tv::kTeam, LDSZ = tv::kLdsRows * tv::lds_ld(RHS::d * (q + 1));
+  __shared__ __attribute__((aligned(16))) double lds[TPB * LDSZ];
+  const int team = threadIdx.x / tv::kTeam;
+  const long i = rows_team_trajectory(blockIdx.x, gridDim.x, team);
+  if (i < P.N) rows_filter_adaptive<RHS, q, EK1>(P, i, lds + team * LDSZ);
 }
 template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kWave) void ek_filter_adaptive_kernel(const FilterParams P) {
@@ -226,11 +240,12 @@ struct LaunchFilter {
   template <class RHS, int q, bool EK1>
   void operator()() {
     const unsigned grid = (unsigned)((P.N + kWave - 1) / kWave);
-    if constexpr (RHS::d * (q + 1) <= kFilterRowsMaxD) {
-      if (!adaptive && P.N < filter_rows_max_n()) {  // small ensemble: 16 lanes per trajectory
-        constexpr long TPB = kWave / kFilterRowsTeam;
+    if constexpr (RHS::d * (q + 1) <= kRowsMaxD) {
+      if (P.N < filter_rows_max_n()) {  // small ensemble: 16 lanes per trajectory
+        constexpr long TPB = kWave / tv::kTeam;
         const unsigned rgrid = (unsigned)(((P.N + TPB - 1) / TPB + 7) / 8 * 8);
-        if (P.everystep) hipLaunchKernelGGL((ek_filter_rows_kernel<RHS, q, EK1, true>), dim3(rgrid), dim3(kWave), 0, s, P);
+        if (adaptive) hipLaunchKernelGGL((ek_filter_rows_adaptive_kernel<RHS, q, EK1>), dim3(rgrid), dim3(kWave), 0, s, P);
+        else if (P.everystep) hipLaunchKernelGGL((ek_filter_rows_kernel<RHS, q, EK1, true>), dim3(rgrid), dim3(kWave), 0, s, P);
         else hipLaunchKernelGGL((ek_filter_rows_kernel<RHS, q, EK1, false>), dim3(rgrid), dim3(kWave), 0, s, P);
         return;
       }

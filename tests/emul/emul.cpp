@@ -11,7 +11,7 @@
 #include "../../odefilters.jl_amd/csrc/filter_team.h"
 #include "../../odefilters.jl_amd/csrc/filter_tiles.h"
 #include "../../odefilters.jl_amd/csrc/sample_lane.h"
-#include "../../odefilters.jl_amd/csrc/filter_rows.h"
+#include "../../odefilters.jl_amd/csrc/rows_filter.h"
 #include <vector>
 #include <cstring>
 
@@ -61,12 +61,12 @@ struct RunFilter {
   void operator()() {
     for (long i = 0; i < P.N; ++i) {
       const long i0 = (i / 64) * 64;
-      if (!adaptive && P.stagger == 9) {  // row-per-lane team filter (filter_rows.h): all lanes of a team, phase by phase
+      if (P.stagger == 9) {  // row-per-lane team filter (rows_filter.h): one 16-lane team per trajectory
         if constexpr (RHS::d * (q + 1) <= 16) {
-          std::vector<double> ws(FRowsWs<RHS::d, q + 1>::size);
-          std::vector<FRow<RHS::d, q + 1>> st(16);
-          if (P.everystep) filter_rows_lane<RHS, q, EK1, true, 16>(P, i, 0, ws.data(), st.data());
-          else filter_rows_lane<RHS, q, EK1, false, 16>(P, i, 0, ws.data(), st.data());
+          std::vector<double> ws(tv::kLdsRows * tv::lds_ld(RHS::d * (q + 1)));
+          if (adaptive) rows_filter_adaptive<RHS, q, EK1>(P, i, ws.data());
+          else if (P.everystep) rows_filter_fixed<RHS, q, EK1, true>(P, i, ws.data());
+          else rows_filter_fixed<RHS, q, EK1, false>(P, i, ws.data());
         }
         continue;
       }
