@@ -11,9 +11,11 @@ buffers are allocated once and stay resident in HBM.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Weak scaling: every rank (GPU) filters its own `--traj` trajectories (global trajectory index
-= rank * traj + i); no exchange while stepping; one RCCL all-gather of the final posterior
-means at the end of each pass (inside the timed region).
+STRONG scaling is the default and the headline (`value`): BASELINE.json's 65 536-trajectory ensemble is split evenly
+over the ranks (contiguous blocks, global trajectory numbering, so every rank count solves the SAME ensemble); no
+exchange while stepping; one RCCL all-gather of the final posterior means at the end of each pass, inside the timed
+region.  With more than one rank the line also carries a `weak_scaling` object: the same loop with 65 536
+trajectories PER GPU (`--mode weak` makes that the headline instead).
 """
 import argparse
 import json
@@ -66,9 +68,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)  # the first launches after allocation run 5-8 % slower (first touch of 48.9 GB, clock ramp)
-    ap.add_argument("--traj", type=int, default=65536, help="trajectories per GPU (weak scaling, the default)")
-    ap.add_argument("--total-traj", type=int, default=0,
-                    help="strong scaling instead: this many trajectories in total, split evenly over the ranks")
+    ap.add_argument("--mode", choices=["strong", "weak"], default="strong",
+                    help="strong (default): --total-traj split over the ranks; weak: --traj per GPU")
+    ap.add_argument("--total-traj", type=int, default=65536, help="ensemble size of the strong-scaling run (BASELINE config 3)")
+    ap.add_argument("--traj", type=int, default=65536, help="trajectories per GPU of the weak-scaling run")
     ap.add_argument("--nsteps", type=int, default=1024, help="solver steps per trajectory (tspan = nsteps * 2^-9)")
     ap.add_argument("--save", choices=["everystep", "final"], default="everystep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -88,72 +91,112 @@ def main():
     d, q = 3, 3
     D = d * (q + 1)
     TRI = D * (D + 1) // 2
-    N, nsteps = args.traj, args.nsteps
-    if args.total_traj:
-        if args.total_traj % world:
-            raise SystemExit("--total-traj must be divisible by the number of ranks")
-        N = args.total_traj // world
+    nsteps = args.nsteps
     everystep = args.save == "everystep"
     n_save = nsteps + 1 if everystep else 1
     dt = 2.0**-9
     tgrid = np.arange(nsteps + 1) * dt
-
-    ctx = pkg.Context("lorenz63", q, 1, N, save_everystep=everystep, smooth=False, device=local, want_loglik=True)
     stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)
-    # resident output buffers owned by torch (so the all-gather reads them in place)
-    mean = torch.empty((n_save, D, N), dtype=torch.float64, device=dev)
-    cov = torch.empty((n_save, TRI, N), dtype=torch.float64, device=dev)
-    ctx.bind_device(0, mean.data_ptr(), mean.numel() * 8)
-    ctx.bind_device(1, cov.data_ptr(), cov.numel() * 8)
-    ctx.set_problem_perturbed([1.0, 0.0, 0.0], [10.0, 28.0, 8.0 / 3.0], 0.0, 1e-2, first_index=rank * N)
 
-    kernel_ms = []
+    def run(mode, steps, warmup):
+        """One timed loop.  Returns (seconds for `steps` passes [max over ranks], kernel ms, N per rank, parity info)."""
+        if mode == "strong":
+            lo, hi = od.shard_bounds(args.total_traj, rank, world)
+            N, first = hi - lo, lo
+        else:
+            N, first = args.traj, rank * args.traj
+        ctx = pkg.Context("lorenz63", q, 1, N, save_everystep=everystep, smooth=False, device=local, want_loglik=True)
+        ctx.set_stream(stream.cuda_stream)
+        # resident output buffers owned by torch (so the all-gather reads them in place)
+        mean = torch.empty((n_save, D, N), dtype=torch.float64, device=dev)
+        cov = torch.empty((n_save, TRI, N), dtype=torch.float64, device=dev)
+        ctx.bind_device(0, mean.data_ptr(), mean.numel() * 8)
+        ctx.bind_device(1, cov.data_ptr(), cov.numel() * 8)
+        ctx.set_problem_perturbed([1.0, 0.0, 0.0], [10.0, 28.0, 8.0 / 3.0], 0.0, 1e-2, first_index=first)
+        n_pad = -(-max(args.total_traj, 1) // world) if mode == "strong" else N  # equal blocks for the all-gather
+        send = torch.zeros((D, n_pad), dtype=torch.float64, device=dev) if world > 1 else None
+        kernel_ms = []
 
-    def one_pass():
-        ctx.solve_fixed(tgrid)  # launches on torch's stream; records hipEvents around the kernel
-        kernel_ms.append(ctx.kernel_time_ms(0)[0])
+        def one_pass():
+            ctx.solve_fixed(tgrid)  # launches on torch's stream; records hipEvents around the kernel
+            kernel_ms.append(ctx.kernel_time_ms(0)[0])
+            if world > 1:
+                send[:, :N].copy_(mean[n_save - 1])
+                return od.allgather_shards(send, world)
+            return mean[n_save - 1]
+
+        def sync_all():
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize(dev)
+
+        for _ in range(warmup):
+            one_pass()
+        kernel_ms.clear()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            final = one_pass()
+        sync_all()
+        el = time.perf_counter() - t0
         if world > 1:
-            return od.allgather_shards(mean[n_save - 1], world)
-        return mean[n_save - 1]
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        finite_ok = bool(torch.isfinite(final).all().item()) and bool((ctx.get(10) == 0).all())
+        # parity inside the bench: final posterior means of a few trajectories of THIS run against the committed
+        # oracle fixture (tests/golden/full_lorenz_fixed.npz: the same ensemble, 1 024 steps), 1e-10 relative
+        parity = None
+        fx_path = os.path.join(ROOT, "tests", "golden", "full_lorenz_fixed.npz")
+        if rank == 0 and os.path.exists(fx_path) and nsteps == 1024:
+            fx = np.load(fx_path)
+            local_mean = mean[n_save - 1].cpu().numpy()
+            worst, n_cmp = 0.0, 0
+            for k, gi in enumerate(fx["idx"]):
+                if first <= gi < first + N:
+                    ref = fx["mean_filt"][k][-1][:d]
+                    worst = max(worst, float(np.abs(local_mean[:d, gi - first] - ref).max() / np.abs(ref).max()))
+                    n_cmp += 1
+            parity = {"max_rel_err_vs_oracle_fixture": worst, "trajectories_compared": n_cmp, "tolerance": 1e-10,
+                      "ok": bool(n_cmp >= 4 and worst <= 1e-10)}
+        k_ms = float(np.mean(kernel_ms))
+        kname = ctx_kernel_name(N, everystep)
+        ctx.close()
+        del mean, cov
+        torch.cuda.empty_cache()
+        return el, k_ms, N, finite_ok, parity, kname
 
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize(dev)
+    def ctx_kernel_name(N, every):  # as rocprofv3 prints it (launcher thresholds of csrc/ek_kernels.h)
+        rows_max = int(os.environ.get("ODEF_FILTER_ROWS_MAX_N", "12288"))
+        if N < rows_max:
+            return "odef::ek_filter_rows_kernel<odef::RhsLorenz63, 3, true, %s>" % ("true" if every else "false")
+        lag = every and N < int(os.environ.get("ODEF_FILTER_LAG_MAX_N", "32768"))
+        return "odef::ek_filter_fixed_kernel<odef::RhsLorenz63, 3, true, %s, %s>" % ("true" if every else "false", "true" if lag else "false")
 
-    for _ in range(args.warmup):
-        one_pass()
-    kernel_ms.clear()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        final = one_pass()
-    sync_all()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        el = float(t.item())
-
-    # sanity inside the bench: the result is finite and the ensemble did something
-    ok = bool(torch.isfinite(final).all().item()) and bool((ctx.get(10) == 0).all())
-
-    total_steps = world * N * nsteps * args.steps
-    value = total_steps / el
-    k_ms = float(np.mean(kernel_ms))
+    el, k_ms, N, finite_ok, parity, kname = run(args.mode, args.steps, args.warmup)
+    total_traj = args.total_traj if args.mode == "strong" else world * N
+    value = total_traj * nsteps * args.steps / el
     alg_bytes = B_ALG_STEP(D) * N * (nsteps + 1 if everystep else 1)
     achieved = alg_bytes / (k_ms * 1e-3)
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             key = f"lorenz63_ek1q3_N{N}_n{nsteps}_{args.save}"
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            if traffic is not None:  # NOT measured in this run: PMC counters need their own rocprofv3 passes
+                traffic_source = "profiles/hbm_traffic.json (separate rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of the same launch)"
         except Exception:
             traffic = None
+    other = None
+    if world > 1:  # the other scaling mode beside the headline
+        om = "weak" if args.mode == "strong" else "strong"
+        el2, k2, N2, _, _, kname2 = run(om, max(2, args.steps // 2), 1)
+        tot2 = args.total_traj if om == "strong" else world * N2
+        other = {"scaling": om, "value": tot2 * nsteps * max(2, args.steps // 2) / el2, "unit": "filter steps/s",
+                 "trajectories_per_gpu": N2, "ms_per_step": el2 / max(2, args.steps // 2) * 1e3, "kernel_ms": k2, "kernel": kname2}
 
     if rank == 0:
         line = {
@@ -165,26 +208,30 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if args.total_traj else "weak",
+            "scaling": args.mode,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"Lorenz-63 d=3, EK1(order=3), dynamic diffusion, fixed dt=2^-9, {N} trajectories per GPU x {nsteps} steps, "
-                            f"save={args.save} (BASELINE.json configs[2]; perturbed u0 via splitmix64)",
-                "trajectories_per_gpu": N, "solver_steps": nsteps, "state_dim": D, "parallelism": f"ensemble-shard x{world}",
+                "workload": f"Lorenz-63 d=3, EK1(order=3), dynamic diffusion, fixed dt=2^-9, {total_traj} trajectories in total = {N} per GPU "
+                            f"x {nsteps} steps, save={args.save} (BASELINE.json configs[2]; perturbed u0 via splitmix64)",
+                "total_trajectories": total_traj, "trajectories_per_gpu": N, "solver_steps": nsteps, "state_dim": D,
+                "parallelism": f"ensemble-shard x{world}",
                 "collective": "one all_gather of final means per pass" if world > 1 else "none",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": traffic,
-                "kernel": "odef::ek_filter_fixed_kernel<odef::RhsLorenz63, 3, true, %s, %s>" % (
-                    "true" if everystep else "false", "true" if (everystep and N < 32768) else "false"),  # name as rocprofv3 prints it
+                "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": kname,
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
-            "parity_ok": ok,
+            "finite_ok": finite_ok,
+            "parity_ok": bool(parity["ok"]) if parity else None,
+            "parity": parity,
         }
+        if other:
+            line[other["scaling"] + "_scaling"] = other
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
@@ -192,7 +239,6 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
-    ctx.close()
 
 
 if __name__ == "__main__":

@@ -32,6 +32,9 @@
  *   odef_smooth_step                predict!, update!, smooth (pure functions)   src/filtering.jl:17,79,136
  *   odef_ibm / odef_preconditioner  ibm(d,q), preconditioner(T,d,q)              src/priors.jl:7-59,
  *                                                                                src/preconditioning.jl:1-17
+ *   odef_group_* / odef_allgather   nothing in the reference (it has no ensemble and no distributed code):
+ *                                   the EnsembleProblem axis sharded over the GPUs of one node by ONE host process, the
+ *                                   per-trajectory path above unchanged on every shard, one RCCL all-gather at the end
  *
  * Error convention: every function returns 0 on success, <0 on API / HIP failure with a
  * message in odef_last_error().  Numerical trouble is per trajectory (RETCODE field) and
@@ -218,6 +221,37 @@ int odef_synchronize(odef_ctx* ctx);
 /* Device time of the last filter (which=0) / smoother (which=1) launch, measured with
  * hipEvents on the launch stream; n_launches = kernels launched by that call. */
 int odef_kernel_time_ms(odef_ctx* ctx, int which, float* ms, int* n_launches);
+
+/* ---- ensemble sharded over the GPUs of one node, single host process -------------------------------
+ * Trajectories are independent, so the ensemble is cut into contiguous blocks, one per device; nothing is exchanged
+ * while stepping; odef_allgather is the ONE collective (ncclAllGather over xGMI, librccl bound with dlopen at the first
+ * call; `ncclCommInitAll`, no MPI, no second process).  A Julia host drives 8 GPUs through these calls alone. */
+typedef struct odef_group odef_group;
+/* block [first, first + count) of shard `shard` out of n_shards: the first n_traj % n_shards shards are one longer */
+int odef_shard_range(int64_t n_traj, int32_t n_shards, int32_t shard, int64_t* first, int64_t* count);
+/* cfg->n_traj is the size of the WHOLE ensemble; cfg->device is ignored; device_ids == NULL: devices 0..n_devices-1 */
+int odef_group_create(odef_group** out, const odef_config* cfg, int32_t n_devices, const int32_t* device_ids);
+void odef_group_destroy(odef_group* g);
+const char* odef_group_last_error(const odef_group* g); /* g may be NULL: last error of odef_group_create */
+int32_t odef_group_size(const odef_group* g);
+odef_ctx* odef_group_ctx(odef_group* g, int32_t shard);  /* the shard's context (owned by the group): odef_get etc. */
+int odef_group_shard(const odef_group* g, int32_t shard, int64_t* first, int64_t* count);
+/* u0[N][d], p[N][n_params] (or shared p) of the whole ensemble in host memory; each shard takes its block */
+int odef_group_set_problem(odef_group* g, const double* u0, const double* p, double t0);
+/* odef_set_problem_perturbed with GLOBAL trajectory numbering: the ensemble does not depend on the number of devices */
+int odef_group_set_problem_perturbed(odef_group* g, const double* base_u0, const double* p, double t0, double scale,
+                                     uint64_t seed, int32_t n_perturbed);
+/* the shards' kernels are launched one after the other and run concurrently; the call returns when all are done */
+int odef_group_solve_fixed(odef_group* g, const double* tgrid, int64_t n_t);
+int odef_group_solve_adaptive(odef_group* g, double t1, double abstol, double reltol, double dt0,
+                              const odef_controller* ctrl, int64_t max_steps);
+int odef_group_smooth(odef_group* g);
+/* All-gather of the FINAL posterior mean of every trajectory (smoothed == 0: filter, record NSAVED-1; != 0: smoothed):
+ * afterwards every device holds [n_shards][D][count_max] doubles (blocks of the shorter shards zero-padded). */
+int odef_allgather(odef_group* g, int smoothed);
+/* the gathered result as device `shard` holds it: host_dst (may be NULL) receives [D][n_traj] with the padding
+ * removed; dev_ptr / dev_bytes (may be NULL) the raw device block */
+int odef_group_get_gathered(odef_group* g, int32_t shard, double* host_dst, void** dev_ptr, size_t* dev_bytes);
 
 /* Constants (host side, for tests and host mirrors). A, Q_L: D x D row-major. */
 int odef_ibm(int d, int q, double* A, double* Q_L);

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -71,6 +72,10 @@ struct odef_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float ms[2] = {0.f, 0.f};
   int nl[2] = {0, 0};
+  // odef_group runs its shards concurrently: with `defer` set, odef_solve_* / odef_smooth return after the launch and
+  // complete_pending() does the wait + timing (pending: 1 = filter, 2 = smoother)
+  bool defer = false;
+  int pending = 0;
   std::string err;
 };
 
@@ -450,6 +455,18 @@ static void fill_params(odef_ctx* c, FilterParams& P) {
   P.retcode = (int*)c->f[ODEF_F_RETCODE].ptr;
 }
 
+static int complete_pending(odef_ctx* c) {
+  if (c->pending == 1) {
+    HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    HIPCHK(c, hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]));
+  } else if (c->pending == 2) {
+    HIPCHK(c, hipEventSynchronize(c->ev[3]));
+    HIPCHK(c, hipEventElapsedTime(&c->ms[1], c->ev[2], c->ev[3]));
+  }
+  c->pending = 0;
+  return 0;
+}
+
 static int finish_filter(odef_ctx* c, int nlaunch) {
   // static diffusion: rescale all covariances by the final global diffusion (src/integrator_utils.jl:4-18)
   if (c->cfg.diffusion != ODEF_DIFFUSION_DYNAMIC) {
@@ -462,12 +479,11 @@ static int finish_filter(odef_ctx* c, int nlaunch) {
   }
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventSynchronize(c->ev[1]));
-  HIPCHK(c, hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]));
   c->nl[0] = nlaunch;
   c->solved = true;
   c->smoothed_done = false;
-  return 0;
+  c->pending = 1;
+  return c->defer ? 0 : complete_pending(c);
 }
 
 int odef_solve_fixed(odef_ctx* c, const double* tgrid, int64_t n_t) {
@@ -647,11 +663,10 @@ int odef_smooth(odef_ctx* c) {
   if (rc) return fail(c, "odef_smooth: no kernel for d %d order %d", c->d, c->q);
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventSynchronize(c->ev[3]));
-  HIPCHK(c, hipEventElapsedTime(&c->ms[1], c->ev[2], c->ev[3]));
   c->nl[1] = 1;
   c->smoothed_done = true;
-  return 0;
+  c->pending = 2;
+  return c->defer ? 0 : complete_pending(c);
 }
 
 int odef_dense_output(odef_ctx* c, const double* tq, int64_t n_q, int smoothed) {
@@ -859,6 +874,296 @@ int odef_preconditioner(int d, int q, double h, double* P_diag) {
   for (int j = 0; j <= q; ++j) {
     for (int i = 0; i < d; ++i) P_diag[j * d + i] = val;
     val *= h;
+  }
+  return 0;
+}
+
+
+/* ---- ensemble sharded over the GPUs of one node (single process) ------------------------------------------------- */
+
+int odef_shard_range(int64_t n_traj, int32_t n_shards, int32_t shard, int64_t* first, int64_t* count) {
+  if (n_traj < 0 || n_shards < 1 || shard < 0 || shard >= n_shards || !first || !count) return -1;
+  // contiguous blocks, the first n_traj % n_shards shards one trajectory longer
+  const int64_t base = n_traj / n_shards, rem = n_traj % n_shards;
+  *first = shard * base + (shard < rem ? shard : rem);
+  *count = base + (shard < rem ? 1 : 0);
+  return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+// librccl is bound at run time (dlopen): the library also has to load where RCCL is not installed, and a group of ONE
+// device needs no collective library at all.
+struct Rccl {
+  void* h = nullptr;
+  int (*CommInitAll)(void**, int, const int*) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool load(std::string& err) {
+    if (h) return true;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names)
+      if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) { err = std::string("librccl.so not loadable: ") + dlerror(); return false; }
+    CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+    GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+    AllGather = (decltype(AllGather))dlsym(h, "ncclAllGather");
+    GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !AllGather || !GetErrorString) {
+      err = "librccl.so lacks an expected symbol";
+      dlclose(h);
+      h = nullptr;
+      return false;
+    }
+    return true;
+  }
+};
+Rccl g_rccl;
+constexpr int kNcclDouble = 8;  // ncclFloat64 (rccl.h)
+
+// final posterior mean of every trajectory of a shard, [D][cnt_max] (padding columns zero): the last record of a fixed
+// grid, record NSAVED-1 of an adaptive solve
+__global__ void pack_final_kernel(const double* __restrict__ mean, const int* __restrict__ nsaved, long n_save_fixed,
+                                  int D, long N, long cnt_max, double* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt_max) return;
+  const long slot = i < N ? (nsaved ? (long)nsaved[i] - 1 : n_save_fixed - 1) : 0;
+  for (int k = 0; k < D; ++k) out[(size_t)k * cnt_max + i] = i < N ? mean[((size_t)slot * D + k) * N + i] : 0.0;
+}
+
+}  // namespace
+
+struct odef_group {
+  std::vector<odef_ctx*> ctx;
+  std::vector<int64_t> first, count;
+  int64_t n_total = 0, cnt_max = 0;
+  int D = 0;
+  std::vector<void*> comm;         // ncclComm_t per device (empty until the first all-gather of a multi-device group)
+  std::vector<double*> send, recv; // per device: [D][cnt_max] and [G][D][cnt_max]
+  bool gathered = false;
+  std::string err;
+};
+
+namespace {
+int gfail(odef_group* g, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (g) g->err = buf;
+  else g_create_error = buf;
+  return -1;
+}
+template <class F>
+int for_all_then_complete(odef_group* g, const char* what, F&& launch) {
+  for (odef_ctx* c : g->ctx) c->defer = true;
+  int rc = 0;
+  size_t launched = 0;
+  for (; launched < g->ctx.size() && rc == 0; ++launched) {
+    rc = launch(g->ctx[launched], (int)launched);
+    if (rc) gfail(g, "%s, shard %zu: %s", what, launched, g->ctx[launched]->err.c_str());
+  }
+  for (size_t k = 0; k < g->ctx.size(); ++k) {
+    odef_ctx* c = g->ctx[k];
+    c->defer = false;
+    if (c->pending && set_device(c) == 0 && complete_pending(c) != 0 && rc == 0)
+      rc = gfail(g, "%s, shard %zu: %s", what, k, c->err.c_str());
+  }
+  g->gathered = false;
+  return rc;
+}
+}  // namespace
+
+extern "C" {
+
+const char* odef_group_last_error(const odef_group* g) { return g ? g->err.c_str() : g_create_error.c_str(); }
+
+int odef_group_create(odef_group** out, const odef_config* cfg, int32_t n_devices, const int32_t* device_ids) {
+  if (!out || !cfg) return gfail(nullptr, "odef_group_create: null argument");
+  *out = nullptr;
+  if (n_devices < 1) return gfail(nullptr, "odef_group_create: n_devices must be >= 1");
+  if (cfg->n_traj < n_devices) return gfail(nullptr, "odef_group_create: fewer trajectories (%lld) than devices (%d)", (long long)cfg->n_traj, n_devices);
+  odef_group* g = new odef_group();
+  g->n_total = cfg->n_traj;
+  for (int k = 0; k < n_devices; ++k) {
+    int64_t first = 0, count = 0;
+    odef_shard_range(cfg->n_traj, n_devices, k, &first, &count);
+    odef_config sc = *cfg;
+    sc.n_traj = count;
+    sc.device = device_ids ? device_ids[k] : k;
+    odef_ctx* c = nullptr;
+    if (odef_create(&c, &sc) != 0) {
+      gfail(nullptr, "odef_group_create: shard %d on device %d: %s", k, sc.device, g_create_error.c_str());
+      odef_group_destroy(g);
+      return -1;
+    }
+    g->ctx.push_back(c);
+    g->first.push_back(first);
+    g->count.push_back(count);
+    if (count > g->cnt_max) g->cnt_max = count;
+    g->D = c->D;
+  }
+  *out = g;
+  return 0;
+}
+
+void odef_group_destroy(odef_group* g) {
+  if (!g) return;
+  for (size_t k = 0; k < g->ctx.size(); ++k) {
+    (void)hipSetDevice(g->ctx[k]->device);
+    if (k < g->comm.size() && g->comm[k] && g_rccl.CommDestroy) g_rccl.CommDestroy(g->comm[k]);
+    if (k < g->send.size() && g->send[k]) (void)hipFree(g->send[k]);
+    if (k < g->recv.size() && g->recv[k]) (void)hipFree(g->recv[k]);
+    odef_destroy(g->ctx[k]);
+  }
+  delete g;
+}
+
+int32_t odef_group_size(const odef_group* g) { return g ? (int32_t)g->ctx.size() : -1; }
+odef_ctx* odef_group_ctx(odef_group* g, int32_t shard) {
+  return (g && shard >= 0 && shard < (int32_t)g->ctx.size()) ? g->ctx[shard] : nullptr;
+}
+int odef_group_shard(const odef_group* g, int32_t shard, int64_t* first, int64_t* count) {
+  if (!g || shard < 0 || shard >= (int32_t)g->ctx.size() || !first || !count) return -1;
+  *first = g->first[shard];
+  *count = g->count[shard];
+  return 0;
+}
+
+int odef_group_set_problem(odef_group* g, const double* u0, const double* p, double t0) {
+  if (!g || !u0) return gfail(g, "odef_group_set_problem: null argument");
+  for (size_t k = 0; k < g->ctx.size(); ++k) {
+    odef_ctx* c = g->ctx[k];
+    const double* pk = (p && !c->cfg.params_shared) ? p + (size_t)g->first[k] * c->np : p;
+    if (odef_set_problem(c, u0 + (size_t)g->first[k] * c->d, pk, t0) != 0)
+      return gfail(g, "odef_group_set_problem, shard %zu: %s", k, c->err.c_str());
+  }
+  return 0;
+}
+
+int odef_group_set_problem_perturbed(odef_group* g, const double* base_u0, const double* p, double t0, double scale,
+                                     uint64_t seed, int32_t n_perturbed) {
+  if (!g) return -1;
+  for (size_t k = 0; k < g->ctx.size(); ++k)  // global numbering: the ensemble does not depend on the number of shards
+    if (odef_set_problem_perturbed(g->ctx[k], base_u0, p, t0, scale, seed, g->first[k], n_perturbed) != 0)
+      return gfail(g, "odef_group_set_problem_perturbed, shard %zu: %s", k, g->ctx[k]->err.c_str());
+  return 0;
+}
+
+int odef_group_solve_fixed(odef_group* g, const double* tgrid, int64_t n_t) {
+  if (!g) return -1;
+  return for_all_then_complete(g, "odef_group_solve_fixed", [&](odef_ctx* c, int) { return odef_solve_fixed(c, tgrid, n_t); });
+}
+int odef_group_solve_adaptive(odef_group* g, double t1, double abstol, double reltol, double dt0, const odef_controller* ctrl,
+                              int64_t max_steps) {
+  if (!g) return -1;
+  return for_all_then_complete(g, "odef_group_solve_adaptive",
+                               [&](odef_ctx* c, int) { return odef_solve_adaptive(c, t1, abstol, reltol, dt0, ctrl, max_steps); });
+}
+int odef_group_smooth(odef_group* g) {
+  if (!g) return -1;
+  return for_all_then_complete(g, "odef_group_smooth", [&](odef_ctx* c, int) { return odef_smooth(c); });
+}
+
+int odef_allgather(odef_group* g, int smoothed) {
+  if (!g) return -1;
+  const int G = (int)g->ctx.size();
+  const size_t blk = (size_t)g->D * (size_t)g->cnt_max;  // doubles per shard block
+  if (g->send.empty()) {
+    g->send.assign(G, nullptr);
+    g->recv.assign(G, nullptr);
+    for (int k = 0; k < G; ++k) {
+      odef_ctx* c = g->ctx[k];
+      if (set_device(c)) return gfail(g, "odef_allgather: %s", c->err.c_str());
+      if (hipMalloc((void**)&g->send[k], blk * sizeof(double)) != hipSuccess ||
+          hipMalloc((void**)&g->recv[k], blk * G * sizeof(double)) != hipSuccess)
+        return gfail(g, "odef_allgather: out of device memory on device %d", c->device);
+    }
+  }
+  // shards that share a device (a test rig with fewer GPUs than shards) cannot form an RCCL communicator: the gather
+  // is then device-to-device copies
+  bool distinct = true;
+  for (int a = 0; a < G; ++a)
+    for (int b = a + 1; b < G; ++b) distinct = distinct && g->ctx[a]->device != g->ctx[b]->device;
+  if (g->comm.empty() && distinct) {
+    std::string lerr;
+    if (g_rccl.load(lerr)) {
+      std::vector<int> devs(G);
+      for (int k = 0; k < G; ++k) devs[k] = g->ctx[k]->device;
+      g->comm.assign(G, nullptr);
+      const int rc = g_rccl.CommInitAll(g->comm.data(), G, devs.data());
+      if (rc != 0) {
+        g->comm.clear();
+        return gfail(g, "odef_allgather: ncclCommInitAll over %d devices failed: %s", G, g_rccl.GetErrorString(rc));
+      }
+    } else if (G > 1) {
+      return gfail(g, "odef_allgather: %s", lerr.c_str());
+    }
+  }
+  // pack the final means of every shard
+  for (int k = 0; k < G; ++k) {
+    odef_ctx* c = g->ctx[k];
+    if (!c->solved) return gfail(g, "odef_allgather: shard %d has not been solved", k);
+    const int f = smoothed ? ODEF_F_SMOOTH_MEAN : ODEF_F_MEAN;
+    if (smoothed && !c->smoothed_done) return gfail(g, "odef_allgather: smoothed means requested but odef_group_smooth has not run");
+    if (set_device(c)) return gfail(g, "odef_allgather: %s", c->err.c_str());
+    const long N = (long)c->cfg.n_traj;
+    hipLaunchKernelGGL(pack_final_kernel, dim3((unsigned)((g->cnt_max + 255) / 256)), dim3(256), 0, c->stream,
+                       (const double*)c->f[f].ptr, c->adaptive ? (const int*)c->f[ODEF_F_NSAVED].ptr : (const int*)nullptr,
+                       c->n_save, c->D, N, (long)g->cnt_max, g->send[k]);
+  }
+  // the one collective of the path: an all-gather over xGMI (RCCL), every device ends with all shards' blocks
+  if (!g->comm.empty()) {
+    int rc = g_rccl.GroupStart();
+    for (int k = 0; k < G && rc == 0; ++k) {
+      (void)hipSetDevice(g->ctx[k]->device);
+      rc = g_rccl.AllGather(g->send[k], g->recv[k], blk, kNcclDouble, g->comm[k], g->ctx[k]->stream);
+    }
+    const int rc2 = g_rccl.GroupEnd();
+    if (rc == 0) rc = rc2;
+    if (rc != 0) return gfail(g, "odef_allgather: ncclAllGather failed: %s", g_rccl.GetErrorString(rc));
+  } else {  // one device without RCCL, or shards sharing a device: the gather is a set of copies
+    for (int k = 0; k < G; ++k)
+      if (hipStreamSynchronize(g->ctx[k]->stream) != hipSuccess) return gfail(g, "odef_allgather: synchronisation failed");
+    for (int k = 0; k < G; ++k)
+      for (int j = 0; j < G; ++j)
+        if (hipMemcpyAsync(g->recv[k] + (size_t)j * blk, g->send[j], blk * sizeof(double), hipMemcpyDeviceToDevice,
+                           g->ctx[k]->stream) != hipSuccess)
+          return gfail(g, "odef_allgather: device copy failed");
+  }
+  for (int k = 0; k < G; ++k) {
+    (void)hipSetDevice(g->ctx[k]->device);
+    if (hipStreamSynchronize(g->ctx[k]->stream) != hipSuccess) return gfail(g, "odef_allgather: synchronisation of device %d failed", g->ctx[k]->device);
+  }
+  g->gathered = true;
+  return 0;
+}
+
+int odef_group_get_gathered(odef_group* g, int32_t shard, double* host_dst /* [D][n_total] */, void** dev_ptr, size_t* dev_bytes) {
+  if (!g || shard < 0 || shard >= (int32_t)g->ctx.size()) return -1;
+  if (!g->gathered) return gfail(g, "odef_group_get_gathered: call odef_allgather first");
+  const int G = (int)g->ctx.size();
+  const size_t blk = (size_t)g->D * (size_t)g->cnt_max;
+  if (dev_ptr) *dev_ptr = g->recv[shard];
+  if (dev_bytes) *dev_bytes = blk * G * sizeof(double);
+  if (host_dst) {
+    odef_ctx* c = g->ctx[shard];
+    if (set_device(c)) return gfail(g, "odef_group_get_gathered: %s", c->err.c_str());
+    std::vector<double> tmp(blk * G);
+    if (hipMemcpy(tmp.data(), g->recv[shard], tmp.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+      return gfail(g, "odef_group_get_gathered: copy from device %d failed", c->device);
+    for (int k = 0; k < G; ++k)  // drop the padding columns of the shorter shards
+      for (int r = 0; r < g->D; ++r)
+        std::memcpy(host_dst + (size_t)r * g->n_total + g->first[k], tmp.data() + (size_t)k * blk + (size_t)r * g->cnt_max,
+                    (size_t)g->count[k] * sizeof(double));
   }
   return 0;
 }

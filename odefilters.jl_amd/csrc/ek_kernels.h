@@ -13,6 +13,7 @@
 #include "filter_team.h"
 #include "filter_tiles.h"
 #include "rows_filter.h"
+#include "rows_smooth.h"
 #include "launch.h"
 
 namespace odef {
@@ -40,31 +41,45 @@ constexpr int kRowsMaxD = tv::kTeam;
 // N <= 65 536 and the row-team kernel (I instructions per wave-step, N / 4 waves) I x 3 ns x max(1, N / 4096);
 // measured crossover: profiles/r02_rows_vs_lane.jsonl.  ODEF_FILTER_ROWS_MAX_N overrides it (read at every launch,
 // so tests can exercise both kernels).
-constexpr long kFilterRowsMaxN = 24576;
+constexpr long kFilterRowsMaxN = 12288;
 inline long filter_rows_max_n() {
   const char* e = getenv("ODEF_FILTER_ROWS_MAX_N");
   return e ? atol(e) : kFilterRowsMaxN;
 }
-__device__ inline long rows_team_trajectory(unsigned block, unsigned nblocks, int team) {
-  const long per = (long)(nblocks / 8u);  // the grid is a multiple of 8 blocks
-  const long g = (long)(block % 8u) * per + (long)(block / 8u);
-  return g * (kWave / tv::kTeam) + team;
+// Workgroup = 4 wavefronts = 16 teams = 16 consecutive trajectories: one 128-byte line per record element (rows_store.h).
+constexpr int kRowsBlock = kRowsWgTeams * tv::kTeam;  // 256 threads
+template <int d, int NB, int STAGE>
+struct RowsLds {  // doubles: 16 teams' exchange rows + the staging image of the record stores
+  static constexpr int team = tv::lds_rows(d, NB) * tv::lds_ld(d * NB);
+  static constexpr int size = kRowsWgTeams * team + STAGE;
+};
+__device__ inline RowsTeam rows_team(long N, double* lds, int team_doubles) {
+  const long per = (long)(gridDim.x / 8u);  // the grid is a multiple of 8 workgroups
+  const long g = (long)(blockIdx.x % 8u) * per + (long)(blockIdx.x / 8u);
+  RowsTeam tm;
+  tm.tcol = (int)(threadIdx.x / tv::kTeam);
+  tm.i16 = g * kRowsWgTeams;
+  const long i = tm.i16 + tm.tcol;
+  tm.valid = i < N;
+  tm.i = tm.valid ? i : N - 1;  // padding teams of the last workgroup compute a duplicate and store nothing
+  tm.lds_team = lds + tm.tcol * team_doubles;
+  tm.stage = lds + kRowsWgTeams * team_doubles;
+  return tm;
 }
+inline unsigned rows_grid(long N) { return (unsigned)(((N + kRowsWgTeams - 1) / kRowsWgTeams + 7) / 8 * 8); }
 template <class RHS, int q, bool EK1, bool EVERY>
-__global__ __launch_bounds__(kWave) void ek_filter_rows_kernel(const FilterParams P) {
-  constexpr int TPB = kWave / tv::kTeam, LDSZ = tv::kLdsRows * tv::lds_ld(RHS::d * (q + 1));
-  __shared__ __attribute__((aligned(16))) double lds[TPB * LDSZ];
-  const int team = threadIdx.x / tv::kTeam;
-  const long i = rows_team_trajectory(blockIdx.x, gridDim.x, team);
-  if (i < P.N) rows_filter_fixed<RHS, q, EK1, EVERY>(P, i, lds + team * LDSZ);
+__global__ __launch_bounds__(kRowsBlock) void ek_filter_rows_kernel(const FilterParams P) {
+  using L = RowsLds<RHS::d, q + 1, EVERY ? RowsSink<RHS::d*(q + 1), true, false>::kStageDoubles : 0>;
+  __shared__ __attribute__((aligned(16))) double lds[L::size];
+  const RowsTeam tm = rows_team(P.N, lds, L::team);
+  if (tm.i16 < P.N) rows_filter_fixed<RHS, q, EK1, EVERY>(P, tm);  // workgroup-uniform
 }
 template <class RHS, int q, bool EK1>
-__global__ __launch_bounds__(kWave) void ek_filter_rows_adaptive_kernel(const FilterParams P) {
-  constexpr int TPB = kWave / tv::kTeam, LDSZ = tv::kLdsRows * tv::lds_ld(RHS::d * (q + 1));
-  __shared__ __attribute__((aligned(16))) double lds[TPB * LDSZ];
-  const int team = threadIdx.x / tv::kTeam;
-  const long i = rows_team_trajectory(blockIdx.x, gridDim.x, team);
-  if (i < P.N) rows_filter_adaptive<RHS, q, EK1>(P, i, lds + team * LDSZ);
+__global__ __launch_bounds__(kRowsBlock) void ek_filter_rows_adaptive_kernel(const FilterParams P) {
+  using L = RowsLds<RHS::d, q + 1, RowsSink<RHS::d*(q + 1), true, true>::kStageDoubles>;
+  __shared__ __attribute__((aligned(16))) double lds[L::size];
+  const RowsTeam tm = rows_team(P.N, lds, L::team);
+  if (tm.i16 < P.N) rows_filter_adaptive<RHS, q, EK1>(P, tm);
 }
 template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kWave) void ek_filter_adaptive_kernel(const FilterParams P) {
@@ -102,6 +117,32 @@ constexpr long kSmoothLaneMinN = 6144;
 inline long smooth_lane_min_n() {
   const char* e = getenv("ODEF_SMOOTH_LANE_MIN_N");
   return e ? atol(e) : kSmoothLaneMinN;
+}
+// Smoother on DPP broadcasts (rows_smooth.h), 16 lanes per trajectory, D <= 16: small and sharded ensembles.
+// ODEF_SMOOTH_ROWS_MAX_N overrides the crossover (read at every launch); which of the three smoothers runs for D <= 12:
+//   N < kSmoothRowsMaxN: this kernel;  otherwise the lane kernel (N >= kSmoothLaneMinN) or the LDS row teams.
+constexpr long kSmoothRowsMaxN = 40960;
+inline long smooth_rows_max_n() {
+  const char* e = getenv("ODEF_SMOOTH_ROWS_MAX_N");
+  return e ? atol(e) : kSmoothRowsMaxN;
+}
+template <int d, int q, bool ADAPT>
+__global__ __launch_bounds__(kRowsBlock) void rts_smooth_bcast_kernel(const SmoothParams P) {
+  using L = RowsLds<d, q + 1, RowsSink<d*(q + 1), false, false>::kStageDoubles>;
+  __shared__ __attribute__((aligned(16))) double lds[L::size];
+  __shared__ int wg_n_hi;
+  const RowsTeam tm = rows_team(P.N, lds, L::team);
+  if (tm.i16 >= P.N) return;  // workgroup-uniform
+  long n_hi = P.n_save;
+  if constexpr (ADAPT) {  // largest record count among the workgroup's trajectories
+    if (threadIdx.x == 0) wg_n_hi = 0;
+    __syncthreads();
+    if (tm.valid && threadIdx.x % tv::kTeam == 0) atomicMax(&wg_n_hi, P.nsaved[tm.i]);
+    __syncthreads();
+    n_hi = wg_n_hi;
+  }
+  RowsSmoother<d, q, ADAPT> sm;
+  sm.run(P, tm, n_hi);
 }
 // Two kernels (fixed grid / adaptive records) so that each gets its own register allocation.
 template <int d, int q, bool ADAPT>
@@ -242,11 +283,10 @@ struct LaunchFilter {
     const unsigned grid = (unsigned)((P.N + kWave - 1) / kWave);
     if constexpr (RHS::d * (q + 1) <= kRowsMaxD) {
       if (P.N < filter_rows_max_n()) {  // small ensemble: 16 lanes per trajectory
-        constexpr long TPB = kWave / tv::kTeam;
-        const unsigned rgrid = (unsigned)(((P.N + TPB - 1) / TPB + 7) / 8 * 8);
-        if (adaptive) hipLaunchKernelGGL((ek_filter_rows_adaptive_kernel<RHS, q, EK1>), dim3(rgrid), dim3(kWave), 0, s, P);
-        else if (P.everystep) hipLaunchKernelGGL((ek_filter_rows_kernel<RHS, q, EK1, true>), dim3(rgrid), dim3(kWave), 0, s, P);
-        else hipLaunchKernelGGL((ek_filter_rows_kernel<RHS, q, EK1, false>), dim3(rgrid), dim3(kWave), 0, s, P);
+        const unsigned rgrid = rows_grid(P.N);
+        if (adaptive) hipLaunchKernelGGL((ek_filter_rows_adaptive_kernel<RHS, q, EK1>), dim3(rgrid), dim3(kRowsBlock), 0, s, P);
+        else if (P.everystep) hipLaunchKernelGGL((ek_filter_rows_kernel<RHS, q, EK1, true>), dim3(rgrid), dim3(kRowsBlock), 0, s, P);
+        else hipLaunchKernelGGL((ek_filter_rows_kernel<RHS, q, EK1, false>), dim3(rgrid), dim3(kRowsBlock), 0, s, P);
         return;
       }
     }
@@ -266,6 +306,16 @@ struct LaunchSmooth {
     // Small state AND a large ensemble: one lane per trajectory.  A small ensemble does not fill the chip that
     // way (N / 64 wavefronts for 1 024 SIMDs); the row-per-lane team kernel gives TPB x fewer trajectories per
     // wavefront, i.e. more wavefronts, and wins below kSmoothLaneMinN.
+    if constexpr (d * (q + 1) <= kRowsMaxD) {
+      if (P.N < smooth_rows_max_n()) {
+        const unsigned rgrid = rows_grid(P.N);
+        if (P.adaptive)
+          hipLaunchKernelGGL((rts_smooth_bcast_kernel<d, q, true>), dim3(rgrid), dim3(kRowsBlock), 0, s, P);
+        else
+          hipLaunchKernelGGL((rts_smooth_bcast_kernel<d, q, false>), dim3(rgrid), dim3(kRowsBlock), 0, s, P);
+        return;
+      }
+    }
     bool lane_kernel = false;
     if constexpr (d * (q + 1) <= kSmoothLaneMaxD) lane_kernel = P.N >= smooth_lane_min_n();
     if constexpr (d * (q + 1) <= kSmoothLaneMaxD) {

@@ -169,7 +169,7 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigne
   double loglik = 0.0, gdiff = 0.0;
   int chol_fix = 0;
   for (long n = 0; n < P.nsteps; ++n) {
-    const double* __restrict__ tab = P.ptab + (size_t)P.tab_idx[n] * kTabStride;  // wave-uniform
+    const GlobalTab tab{P.ptab + (size_t)uniform_load(P.tab_idx + n) * kTabStride};  // wave-uniform, scalar loads
     double m2[D], C2[TRI], es[d];
     StepAux aux;
     aux.chol_fix = 0;
@@ -292,8 +292,9 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
     h = fmin(h, ct.dtmax);
     h = fmin(h, P.t1 - t);  // tstop clipping
     if (!(h > ct.dtmin)) { ret = 2; break; }  // DtLessThanMin
-    double tab[kTabStride];
-    precond_fill<NB>(h, precond_val<q>(h), tab);
+    double tabv[kTabStride];
+    precond_fill<NB>(h, precond_val<q>(h), tabv);
+    const LocalTab tab{tabv};
     double es[d];
     StepAux aux;
     aux.chol_fix = 0;

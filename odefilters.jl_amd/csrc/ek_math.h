@@ -322,8 +322,8 @@ struct EKStep {
   // `sink.mean(v)` / `sink.cov(v)` receive the un-preconditioned results in storage order as soon as each
   // value exists; `sink.tick()` is called at ~110 points spread evenly over the arithmetic of the step (never
   // inside a run-time branch), so that a sink can spread its stores over the step (LaggedSink, ek_lane.h).
-  template <class Sink>
-  __device__ static inline void run(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab,
+  template <class Sink, class Tab>
+  __device__ static inline void run(const PriorConsts& pc, const double* __restrict__ p, const Tab& tab,
                                     int fixed_diffusion, bool want_loglik, int success_iter, double prev_global,
                                     const double (&m)[D], const double (&C)[TRI], double (&m_out)[D],
                                     double (&C_out)[TRI], double (&err_scale)[d], StepAux& aux, Sink& sink) {

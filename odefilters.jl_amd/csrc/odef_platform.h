@@ -41,3 +41,30 @@ using enable_if_t = typename enable_if<B, T>::type;
 #include <math.h>
 #include <type_traits>
 #endif
+
+// A load whose address is the same in every lane, from memory nobody writes while the kernel runs (time grid,
+// preconditioner tables).  On the device it goes through the constant address space, i.e. an s_load on the scalar
+// cache: counted in lgkmcnt, NOT in vmcnt.  As an ordinary (vector) global load inside a time loop that also stores
+// records, its s_waitcnt vmcnt(0) waited for every record store of the previous step as well -- one full
+// store round trip per step, found in the ISA of both filter kernels.
+namespace odef {
+#if defined(ODEF_HOST_EMUL)
+template <class T>
+inline T uniform_load(const T* p) { return *p; }
+#else
+template <class T>
+__device__ __attribute__((always_inline)) inline T uniform_load(const T* p) {
+  return *(const __attribute__((address_space(4))) T*)(p);
+}
+#endif
+// Preconditioner table of a step (precond_fill, ek_math.h): in global memory, shared by all trajectories (fixed grids) ...
+struct GlobalTab {
+  const double* p;
+  __device__ inline double operator[](int k) const { return uniform_load(p + k); }
+};
+// ... or in the lane's own registers (adaptive steps)
+struct LocalTab {
+  const double* p;
+  __device__ inline double operator[](int k) const { return p[k]; }
+};
+}  // namespace odef

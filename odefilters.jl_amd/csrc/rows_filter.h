@@ -26,6 +26,7 @@
 #pragma once
 #include "ek_lane.h"
 #include "team_vec.h"
+#include "rows_store.h"
 
 namespace odef {
 
@@ -72,6 +73,28 @@ __device__ inline void ldl_small(const double (&S)[n][n], double (&L)[n][n], dou
   }
 }
 
+// P(h) = diag(h^(j-q-1/2)) and its inverse for a step size that differs from trajectory to trajectory (adaptive steps;
+// src/preconditioning.jl:1-17): running products from h^(-q-1/2) like the reference's, the reciprocals as a second
+// running product (inv(::Diagonal) to within an ulp) -- no division, no libm pow: the table is rebuilt by all 16 lanes
+// of a team at every attempted step.
+template <int q, int NB>
+__device__ inline void rows_precond_table(double h, double* tab) {
+  double hq = 1.0;
+#pragma unroll
+  for (int k = 0; k < q; ++k) hq *= h;
+  double sh, rsh;
+  sqrt_and_rsqrt(h, sh, rsh);
+  double val = rsh * rcp_pos(hq), ival = hq * sh;
+  const double rh = rcp_pos(h);
+#pragma unroll
+  for (int J = 0; J < NB; ++J) {
+    tab[kTabPJ + J] = val;
+    tab[kTabPIJ + J] = ival;
+    val *= h;
+    ival *= rh;
+  }
+}
+
 // Lane constants of a team: what lane r = (J, a) = (r / d, r % d) multiplies with.
 template <int d, int NB>
 struct RowsConsts {
@@ -103,20 +126,15 @@ struct RowsScale {
   double pjv[NB], pijv[NB];  // P block values and their reciprocals (team-uniform)
   tv::TV pj, pij;            // the lane's own entry (1 in the idle lanes)
   tv::TV f[NB], g[NB];       // f[K] = pj * pjv[K] (precondition row entries of block K), g[K] = pij * pijv[K]
-  __device__ inline void set(const double* tab) {  // tab: one precond_fill table
-    double tj[tv::kTeam], ti[tv::kTeam];
+  template <class Tab>
+  __device__ inline void set(const Tab& tab) {  // tab: one precond_fill table
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
       pjv[J] = tab[kTabPJ + J];
       pijv[J] = tab[kTabPIJ + J];
     }
-#pragma unroll
-    for (int r = 0; r < tv::kTeam; ++r) {
-      tj[r] = (r < d * NB) ? pjv[(r / d) % NB] : 1.0;
-      ti[r] = (r < d * NB) ? pijv[(r / d) % NB] : 1.0;
-    }
-    pj = tv::lane_table(tj, tv::kTeam, 1.0);
-    pij = tv::lane_table(ti, tv::kTeam, 1.0);
+    pj = tv::block_table<d, NB>(pjv, 1.0);
+    pij = tv::block_table<d, NB>(pijv, 1.0);
 #pragma unroll
     for (int K = 0; K < NB; ++K) {
       f[K] = pj * pjv[K];
@@ -128,6 +146,7 @@ struct RowsScale {
 template <class RHS, int q, bool IS_EK1>
 struct RowsStep {
   static constexpr int d = RHS::d, NB = q + 1, D = d * NB, LD = tv::lds_ld(D);
+  static constexpr int kLdsDoubles = tv::lds_rows(d, NB) * LD;  // the team's exchange rows
   static_assert(D <= tv::kTeam, "row-per-lane filter: one lane per state component");
   static_assert(NB >= 2, "order >= 1");
   using TV = tv::TV;
@@ -152,11 +171,10 @@ struct RowsStep {
     });
     // measure! (src/perform_step.jl:95-132), team-uniform
     double up[d], e1[d], du[d], z[d];
-    static_for<0, d>([&](auto ac) {
-      constexpr int a = decltype(ac)::value;
-      up[a] = pi0 * tv::bcast<a>(mp);
-      e1[a] = tv::bcast<d + a>(mp);
-    });
+    tv::bcast_lanes<0, d>(mp, up);
+    tv::bcast_lanes<d, d>(mp, e1);
+#pragma unroll
+    for (int a = 0; a < d; ++a) up[a] = pi0 * up[a];
     RHS::f(up, pl, du);
 #pragma unroll
     for (int a = 0; a < d; ++a) z[a] = pi1 * e1[a] - du[a];
@@ -389,15 +407,6 @@ struct RowsRecord {
   }
 };
 
-// true when any component of the mean is NaN or infinite (team-uniform)
-template <int D>
-__device__ inline bool rows_nonfinite(const tv::TV& m) {
-  const tv::TV flag = tv::nonfinite_flag(m);
-  double bad = 0.0;
-  static_for<0, D>([&](auto kc) { bad += tv::bcast<decltype(kc)::value>(flag); });
-  return bad != 0.0;
-}
-
 template <class RHS, int q>
 __device__ inline void rows_initial_state(const FilterParams& P, long i, double (&pl)[RHS::np > 0 ? RHS::np : 1],
                                           double (&u0)[RHS::d], tv::TV& m, tv::TV (&xr)[RHS::d * (q + 1)]) {
@@ -413,30 +422,35 @@ __device__ inline void rows_initial_state(const FilterParams& P, long i, double 
   for (int c = 0; c < D; ++c) xr[c] = tv::splat(0.0);
 }
 
-// Whole fixed-grid time loop of trajectory i (OrdinaryDiffEq's solve! loop on the device).
+// Whole fixed-grid time loop of the team's trajectory (OrdinaryDiffEq's solve! loop on the device).
+// Workgroup-collective when EVERY (rows_store.h): all 16 teams of the workgroup run the same number of steps.
 template <class RHS, int q, bool IS_EK1, bool EVERY>
-__device__ inline void rows_filter_fixed(const FilterParams& P, long i, double* __restrict__ lds_team) {
+__device__ inline void rows_filter_fixed(const FilterParams& P, const RowsTeam& tm) {
   using S = RowsStep<RHS, q, IS_EK1>;
   constexpr int d = S::d, NB = S::NB, D = S::D, np = RHS::np;
-  const tv::Lds lds{lds_team};
-  tv::lds_clear(lds, S::LD);
+  const long i = tm.i;
+  const tv::Lds lds{tm.lds_team};
+  tv::lds_clear(lds, S::kLdsDoubles);
   double pl[np > 0 ? np : 1], u0[d];
   tv::TV m, xr[D];
   rows_initial_state<RHS, q>(P, i, pl, u0, m, xr);
   RowsConsts<d, NB> lc;
   lc.init(P.pc);
-  RowsRecord<D> rec;
-  rec.init(P.N, i);
-  if constexpr (EVERY) rec.store(P, 0, m, xr, 0.0);
+  RowsSink<D, true, false> sink;
+  if constexpr (EVERY) {
+    sink.init(tm, P.N, S::kLdsDoubles, S::LD, P.mean, P.cov, P.diff, nullptr);
+    sink.stage_cov(lds, S::LD, xr);
+    sink.put(0, tm.valid, false, m, xr, 0.0, 0.0);
+  }
 
   RowsScale<d, NB> sc;
   int cur_tab = -1;
   double loglik = 0.0, gdiff = 0.0;
   int chol_fix = 0;
   for (long n = 0; n < P.nsteps; ++n) {
-    const int ti = P.tab_idx[n];  // wave-uniform
-    if (ti != cur_tab) {          // the lanes' scale factors change only when the step size does
-      sc.set(P.ptab + (size_t)ti * kTabStride);
+    const int ti = uniform_load(P.tab_idx + n);  // wave-uniform, scalar load
+    if (ti != cur_tab) {                          // the lanes' scale factors change only when the step size does
+      sc.set(GlobalTab{P.ptab + (size_t)ti * kTabStride});
       cur_tab = ti;
     }
     double es[d];
@@ -446,12 +460,18 @@ __device__ inline void rows_filter_fixed(const FilterParams& P, long i, double* 
     loglik += aux.loglik;
     gdiff = aux.sigma2_global;
     chol_fix += aux.chol_fix;
-    if constexpr (EVERY) rec.store(P, n + 1, m, xr, gdiff);
+    if constexpr (EVERY) sink.put(n + 1, tm.valid, false, m, xr, gdiff, 0.0);
   }
-  if constexpr (!EVERY) rec.store(P, 0, m, xr, gdiff);
+  if constexpr (!EVERY) {
+    if (tm.valid) {  // one record per solve: stored directly (32-byte pieces, once)
+      RowsRecord<D> rec;
+      rec.init(P.N, i);
+      rec.store(P, 0, m, xr, gdiff);
+    }
+  }
   (void)chol_fix;
-  const bool bad = rows_nonfinite<D>(m);
-  if (tv::is_lane0()) {
+  const bool bad = tv::team_any(tv::nonfinite_flag(m));
+  if (tm.valid && tv::is_lane0()) {
     P.loglik[i] = loglik;
     P.naccept[i] = (int)P.nsteps;
     P.nreject[i] = 0;
@@ -462,106 +482,132 @@ __device__ inline void rows_filter_fixed(const FilterParams& P, long i, double* 
   }
 }
 
-// Adaptive filter of trajectory i: perform_step! + error estimate (src/perform_step.jl:78-92) + OrdinaryDiffEq's PI
-// controller (third-party; exponents src/alg_utils.jl:23-24), exactly as filter_adaptive_lane (ek_lane.h) -- same record
+// Adaptive filter of the team's trajectory: perform_step! + error estimate (src/perform_step.jl:78-92) + OrdinaryDiffEq's
+// PI controller (third-party; exponents src/alg_utils.jl:23-24), as filter_adaptive_lane (ek_lane.h) -- same record
 // layout (one record per ATTEMPTED step, a rejected attempt repeats the old state at the old time), same quirks
 // (commit on EEst < 1, integ.u overwritten on rejection, a rejected step leaves P^-1 (P x)).  The previous state stays
-// in registers, so a rejection re-reads nothing.
+// in registers, so a rejection re-reads nothing.  The d x d controller algebra is replicated in all 16 lanes of a team,
+// so it is kept short: reciprocals by rcp_pos, log(qold) carried from the previous attempt, q11 only when rejected.
+// The loop is workgroup-uniform: it runs until no team of the workgroup wants another attempt (RowsSink::put).
 template <class RHS, int q, bool IS_EK1>
-__device__ inline void rows_filter_adaptive(const FilterParams& P, long i, double* __restrict__ lds_team) {
+__device__ inline void rows_filter_adaptive(const FilterParams& P, const RowsTeam& tm) {
   using S = RowsStep<RHS, q, IS_EK1>;
   constexpr int d = S::d, NB = S::NB, D = S::D, np = RHS::np;
-  const tv::Lds lds{lds_team};
-  tv::lds_clear(lds, S::LD);
+  const long i = tm.i;
+  const tv::Lds lds{tm.lds_team};
+  tv::lds_clear(lds, S::kLdsDoubles);
   double pl[np > 0 ? np : 1], u0[d];
   tv::TV m, xr[D];
   rows_initial_state<RHS, q>(P, i, pl, u0, m, xr);
   RowsConsts<d, NB> lc;
   lc.init(P.pc);
-  RowsRecord<D> rec;
-  rec.init(P.N, i);
-  rec.store(P, 0, m, xr, 0.0);
-  rec.store_time(P, 0, P.t0);
+  RowsSink<D, true, true> sink;
+  sink.init(tm, P.N, S::kLdsDoubles, S::LD, P.mean, P.cov, P.diff, P.tsave);
+  sink.stage_cov(lds, S::LD, xr);
 
   double ucur[d];
 #pragma unroll
   for (int a = 0; a < d; ++a) ucur[a] = u0[a];
   const Controller& ct = P.ctrl;
-  double t = P.t0, h = P.dt0, qold = ct.qoldinit, q11 = 1.0;
+  double t = P.t0, h = P.dt0, qold = ct.qoldinit, log_qold = log(ct.qoldinit), log_eest = 0.0;
   double loglik = 0.0, gdiff = 0.0;
   int naccept = 0, nreject = 0, nsaved = 1, ret = 0;
   const long max_attempts = 20 * P.max_save + 1000;
   long attempts = 0;
   RowsScale<d, NB> sc;
-  while (t < P.t1) {
-    if (nsaved >= P.max_save || attempts >= max_attempts) { ret = 1; break; }  // MaxIters
-    ++attempts;
-    h = fmin(h, ct.dtmax);
-    h = fmin(h, P.t1 - t);  // tstop clipping
-    if (!(h > ct.dtmin)) { ret = 2; break; }  // DtLessThanMin
-    double tab[kTabStride];
-    precond_fill<NB>(h, precond_val<q>(h), tab);
-    sc.set(tab);
-    tv::TV m_old = m, x_old[D];
-#pragma unroll
-    for (int c = 0; c < D; ++c) x_old[c] = xr[c];
-    double es[d];
-    StepAux aux;
-    aux.chol_fix = 0;
-    S::run(P.pc, lc, sc, pl, P.fixed_diffusion, P.want_loglik != 0, naccept, gdiff, lds, m, xr, es, aux);
-    // DiffEqBase.calculate_residuals! + ODE_DEFAULT_NORM (src/perform_step.jl:78-84)
-    double unew[d];
-    static_for<0, d>([&](auto ac) {
-      constexpr int a = decltype(ac)::value;
-      unew[a] = tv::bcast<a>(m);
-    });
-    double acc = 0.0;
-#pragma unroll
-    for (int r = 0; r < d; ++r) {
-      const double e = h * es[r] / (P.abstol + fmax(fabs(ucur[r]), fabs(unew[r])) * P.reltol);
-      acc += e * e;
+  bool active = tm.valid && t < P.t1;
+  bool any = sink.put(0, tm.valid, active, m, xr, 0.0, P.t0);
+  for (long slot = 1; any; ++slot) {
+    bool store = false;
+    if (active) {
+      if (nsaved >= P.max_save || attempts >= max_attempts) {
+        ret = 1;  // MaxIters
+        active = false;
+      }
     }
-    double EEst = sqrt(acc / d);
-    if (!(EEst == EEst) || !(fabs(EEst) <= 1.79769313486231570815e+308)) EEst = INFINITY;
+    if (active) {
+      ++attempts;
+      h = fmin(h, ct.dtmax);
+      h = fmin(h, P.t1 - t);  // tstop clipping
+      if (!(h > ct.dtmin)) {
+        ret = 2;  // DtLessThanMin
+        active = false;
+      }
+    }
+    if (active) {
+      // P(h) (src/preconditioning.jl:1-17): h^(-q-1/2) and the running products; reciprocals for inv(P)
+      {
+        double tab[kTabStride];
+        rows_precond_table<q, NB>(h, tab);
+        sc.set(LocalTab{tab});
+      }
+      const tv::TV m_old = m;
+      tv::TV x_old[D];
 #pragma unroll
-    for (int r = 0; r < d; ++r) ucur[r] = unew[r];  // integ.u .= u_filt (src/perform_step.jl:86), also when rejected
-    // stepsize_controller! (PI)
-    double qq;
-    if (EEst == 0.0) {
-      qq = 1.0 / ct.qmax;
-    } else {
-      q11 = exp(ct.beta1 * log(EEst));
-      qq = q11 * exp(-ct.beta2 * log(qold));
-      qq = fmax(1.0 / ct.qmax, fmin(1.0 / ct.qmin, qq / ct.gamma));
-    }
-    const bool accepted = EEst <= 1.0;  // OrdinaryDiffEq accepts on <=
-    if (!(EEst < 1.0)) {
-      // x_filt is not committed (src/perform_step.jl:89): cache.x stays P^-1 (P x) of the old state (:73)
-      m = sc.pij * (sc.pj * m_old);
+      for (int c = 0; c < D; ++c) x_old[c] = xr[c];
+      double es[d];
+      StepAux aux;
+      aux.chol_fix = 0;
+      S::run(P.pc, lc, sc, pl, P.fixed_diffusion, P.want_loglik != 0, naccept, gdiff, lds, m, xr, es, aux);
+      // DiffEqBase.calculate_residuals! + ODE_DEFAULT_NORM (src/perform_step.jl:78-84)
+      double unew[d];
+      tv::bcast_lanes<0, d>(m, unew);
+      double acc = 0.0;
 #pragma unroll
-      for (int c = 0; c < D; ++c) xr[c] = x_old[c];
+      for (int r = 0; r < d; ++r) {
+        const double e = h * es[r] * rcp_pos(P.abstol + fmax(fabs(ucur[r]), fabs(unew[r])) * P.reltol);
+        acc += e * e;
+      }
+      double EEst = sqrt(acc * (1.0 / d));
+      if (!(EEst == EEst) || !(fabs(EEst) <= 1.79769313486231570815e+308)) EEst = INFINITY;
+#pragma unroll
+      for (int r = 0; r < d; ++r) ucur[r] = unew[r];  // integ.u .= u_filt (src/perform_step.jl:86), also when rejected
+      // stepsize_controller! (PI): q = EEst^beta1 / qold^beta2 / gamma, clamped
+      double qq;
+      if (EEst == 0.0) {
+        qq = 1.0 / ct.qmax;
+      } else {
+        log_eest = log(EEst);
+        qq = exp(ct.beta1 * log_eest - ct.beta2 * log_qold);
+        qq = fmax(1.0 / ct.qmax, fmin(1.0 / ct.qmin, qq / ct.gamma));
+      }
+      const bool accepted = EEst <= 1.0;  // OrdinaryDiffEq accepts on <=
+      if (!(EEst < 1.0)) {
+        // x_filt is not committed (src/perform_step.jl:89): cache.x stays P^-1 (P x) of the old state (:73)
+        m = sc.pij * (sc.pj * m_old);
+#pragma unroll
+        for (int c = 0; c < D; ++c) xr[c] = x_old[c];
+        sink.stage_cov(lds, S::LD, xr);  // the exchange rows hold the rejected candidate
+      }
+      if (accepted) {
+        if (EEst < 1.0) loglik += aux.loglik;
+        if (qq <= ct.qsteady_max && qq >= ct.qsteady_min) qq = 1.0;
+        qold = fmax(EEst, ct.qoldinit);
+        log_qold = (EEst > ct.qoldinit) ? log_eest : log(ct.qoldinit);
+        double tn = t + h;
+        if (fabs(tn - P.t1) < 100.0 * 2.220446049250313e-16 * fmax(fabs(tn), fabs(P.t1))) tn = P.t1;
+        t = tn;
+        gdiff = aux.sigma2_global;
+        ++naccept;
+        h = h / qq;
+      } else {
+        ++nreject;
+        const double q11 = (EEst == 0.0) ? 1.0 : exp(ct.beta1 * log_eest);
+        h = h / fmin(1.0 / ct.qmin, q11 / ct.gamma);
+      }
+      // accepted: the new state at the new time; rejected: the old state again at the old time
+      store = true;
+      ++nsaved;
+      if (accepted && tv::team_any(tv::nonfinite_flag(m))) {
+        ret = 3;
+        active = false;
+      }
+      if (!(t < P.t1)) active = false;
     }
-    if (accepted) {
-      if (EEst < 1.0) loglik += aux.loglik;
-      if (qq <= ct.qsteady_max && qq >= ct.qsteady_min) qq = 1.0;
-      qold = fmax(EEst, ct.qoldinit);
-      double tn = t + h;
-      if (fabs(tn - P.t1) < 100.0 * 2.220446049250313e-16 * fmax(fabs(tn), fabs(P.t1))) tn = P.t1;
-      t = tn;
-      gdiff = aux.sigma2_global;
-      ++naccept;
-      h = h / qq;
-    } else {
-      ++nreject;
-      h = h / fmin(1.0 / ct.qmin, q11 / ct.gamma);
-    }
-    // accepted: the new state at the new time; rejected: the old state again at the old time
-    rec.store(P, nsaved, m, xr, gdiff);
-    rec.store_time(P, nsaved, t);
-    ++nsaved;
-    if (accepted && rows_nonfinite<D>(m)) { ret = 3; break; }
+    any = sink.put(slot, store, active, m, xr, gdiff, t);
   }
-  if (tv::is_lane0()) {
+  (void)qold;
+  if (tm.valid && tv::is_lane0()) {
     P.loglik[i] = loglik;
     P.naccept[i] = naccept;
     P.nreject[i] = nreject;

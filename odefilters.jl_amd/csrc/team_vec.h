@@ -32,8 +32,8 @@ constexpr int kTeam = 16;
 // leading dimension (doubles) of the team's LDS rows: >= D, == 2 (mod 4) -- even, so that rows start on 16-byte
 // boundaries (ds_read/write_b128), and 4 (mod 8) dwords, so that a column access of 16 lanes is at most 2-way conflicted
 __host__ __device__ constexpr int lds_ld(int D) { return D + ((2 - D % 4) + 4) % 4; }
-// rows of the team's LDS image: 16 written rows + the rows a shifted read (up to 15 lanes ahead) can touch, kept zero
-constexpr int kLdsRows = 2 * kTeam - 1;
+// rows of the team's LDS image: 16 written rows + the rows a shifted read ((NB - 1) d lanes ahead) can touch, kept zero
+__host__ __device__ constexpr int lds_rows(int d, int NB) { return kTeam + (NB - 1) * d; }
 
 #ifdef ODEF_HOST_EMUL
 // ------------------------------------------------------------------------------------------------ host emulation
@@ -122,18 +122,62 @@ template <int K>
 inline void fma_bc(TV& acc, const TV& src, double b) { fma_bc<K>(acc, src, splat(b)); }
 template <int K>
 inline void fnma_bc(TV& acc, const TV& src, double b) { fnma_bc<K>(acc, src, splat(b)); }
+// true if the flag (0.0 / 1.0) is set in any lane of the team
+inline bool team_any(const TV& flag) {
+  bool a = false;
+  for (int l = 0; l < kTeam; ++l) a = a || flag.v[l] != 0.0;
+  return a;
+}
+// out[j] = bcast<K0 + j>(src), j < n
+template <int K0, int n>
+inline void bcast_lanes(const TV& src, double* out) {
+  for (int j = 0; j < n; ++j) out[j] = src.v[K0 + j];
+}
 // out[j] = bcast<K>(src[j]), j < n
 template <int K, int n>
 inline void bcast_vec(const TV* src, double* out) {
   for (int j = 0; j < n; ++j) out[j] = src[j].v[K];
 }
-// acc[c] -= bcast<c>(src) * b for c = C0 .. C0 + n - 1: a rank-one update of the own row, column c scaled by lane c's src
-template <int C0, int n>
-inline void fnma_bc_cols(TV* acc, const TV& src, const TV& b) {
+// Grouped broadcast-FMAs (NEG: subtract).  On the device each group of four shares one s_nop.
+//   cols :  acc[c] += bcast<c>(src) * b          c = C0 .. C0+n-1   (rank-one update of the own row; pivot-column step)
+//   rows :  acc[j] += bcast<K>(src[j]) * b       j = 0 .. n-1       (row K of a matrix times the lane's scalar b)
+//   dot  :  acc    += sum_j bcast<K>(src[j]) * b[j]                 (forward substitution: row K of L against the lane's vector)
+//   lanes:  acc    += sum_c bcast<c>(src) * b[c] c = C0 .. C0+n-1   (backward substitution / matrix-vector product)
+template <bool NEG, int K>
+inline void fb1(TV& acc, const TV& src, const TV& b) {
+  if constexpr (NEG) fnma_bc<K>(acc, src, b);
+  else fma_bc<K>(acc, src, b);
+}
+template <bool NEG, int C0, int n>
+inline void fb_cols(TV* acc, const TV& src, const TV& b) {
   if constexpr (n > 0) {
-    fnma_bc<C0>(acc[C0], src, b);
-    fnma_bc_cols<C0 + 1, n - 1>(acc, src, b);
+    fb1<NEG, C0>(acc[C0], src, b);
+    fb_cols<NEG, C0 + 1, n - 1>(acc, src, b);
   }
+}
+template <bool NEG, int K, int n>
+inline void fb_rows(TV* acc, const TV* src, const TV& b) {
+  for (int j = 0; j < n; ++j) fb1<NEG, K>(acc[j], src[j], b);
+}
+template <bool NEG, int K, int n>
+inline void fb_dot(TV& acc, const TV* src, const TV* b) {
+  for (int j = 0; j < n; ++j) fb1<NEG, K>(acc, src[j], b[j]);
+}
+template <bool NEG, int C0, int n>
+inline void fb_lanes(TV& acc, const TV& src, const TV* b) {
+  if constexpr (n > 0) {
+    fb1<NEG, C0>(acc, src, b[C0]);
+    fb_lanes<NEG, C0 + 1, n - 1>(acc, src, b);
+  }
+}
+template <int C0, int n>
+inline void fnma_bc_cols(TV* acc, const TV& src, const TV& b) { fb_cols<true, C0, n>(acc, src, b); }
+// lane r -> vals[r / d] for r < d * NB, `fill` in the idle lanes
+template <int d, int NB>
+inline TV block_table(const double* vals, double fill) {
+  TV r;
+  for (int l = 0; l < kTeam; ++l) r.v[l] = l < d * NB ? vals[l / d] : fill;
+  return r;
 }
 // value of lane r + S (0 beyond the team)
 template <int S>
@@ -145,10 +189,10 @@ inline TV shl(const TV& x) {
 
 // the team's LDS rows
 struct Lds {
-  double* p;  // [kLdsRows][LD]
+  double* p;  // [lds_rows][LD]
 };
-inline void lds_clear(const Lds& m, int LD) {
-  for (int k = 0; k < kLdsRows * LD; ++k) m.p[k] = 0.0;
+inline void lds_clear(const Lds& m, int doubles) {
+  for (int k = 0; k < doubles; ++k) m.p[k] = 0.0;
 }
 // lane r writes its row: m[r][c] = row[c]
 template <int n>
@@ -207,7 +251,8 @@ inline TV field_load(const Field& f, const TU& off) {
   return r;
 }
 inline void field_store_uniform(const Field& f, const TU& off, double x) { field_store(f, off, splat(x)); }
-inline void field_wait() {}
+// element [row][i] of a field slot laid out [rows][N], the same for every lane of the team
+inline double field_load_uniform(const Field& f, size_t N, long i, int row) { return f.base[(size_t)row * N + (size_t)i]; }
 
 #else
 // ------------------------------------------------------------------------------------------------------ gfx950
@@ -247,6 +292,41 @@ template <int K>
 ODEF_TV_INLINE void fnma_bc(double& acc, double src, double b) {
   asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(b), "n"(K));
 }
+// true if the flag (0.0 / 1.0) is set in any lane of the team: one ballot, the team's 16 bits of it
+ODEF_TV_INLINE bool team_any(double flag) {
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(flag != 0.0);
+  const unsigned sh = (threadIdx.x & 48u);
+  return ((b >> sh) & 0xFFFFull) != 0ull;
+}
+// out[j] = bcast<K0 + j>(src), j < n: up to four v_mov_b64_dpp behind one s_nop
+template <int K0, int n>
+ODEF_TV_INLINE void bcast_lanes(double src, double* out) {
+  if constexpr (n >= 4) {
+    asm("s_nop 1\n\t"
+        "v_mov_b64_dpp %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %1, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %2, %4 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %3, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
+        : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3])
+        : "v"(src), "n"(K0), "n"(K0 + 1), "n"(K0 + 2), "n"(K0 + 3));
+    bcast_lanes<K0 + 4, n - 4>(src, out + 4);
+  } else if constexpr (n == 3) {
+    asm("s_nop 1\n\t"
+        "v_mov_b64_dpp %0, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %1, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %2, %3 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+        : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2])
+        : "v"(src), "n"(K0), "n"(K0 + 1), "n"(K0 + 2));
+  } else if constexpr (n == 2) {
+    asm("s_nop 1\n\t"
+        "v_mov_b64_dpp %0, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+        : "=&v"(out[0]), "=&v"(out[1])
+        : "v"(src), "n"(K0), "n"(K0 + 1));
+  } else if constexpr (n == 1) {
+    out[0] = bcast<K0>(src);
+  }
+}
 // out[j] = bcast<K>(src[j]), j < n: up to four v_mov_b64_dpp behind one s_nop
 template <int K, int n>
 ODEF_TV_INLINE void bcast_vec(const double* src, double* out) {
@@ -276,23 +356,101 @@ ODEF_TV_INLINE void bcast_vec(const double* src, double* out) {
     out[0] = bcast<K>(src[0]);
   }
 }
-// acc[c] -= bcast<c>(src) * b for c = C0 .. C0 + n - 1, four v_fmac_f64_dpp behind ONE s_nop (the accumulators are
-// not DPP sources, so nothing inside a group needs a wait state)
-template <int C0, int n>
-ODEF_TV_INLINE void fnma_bc_cols(double* acc, double src, double b) {
+// Grouped broadcast-FMAs (see the host section for what each computes): four v_fmac_f64_dpp behind ONE s_nop.  Inside a
+// group no instruction reads through DPP a register the group writes (the accumulators are never DPP sources), so
+// nothing inside needs a wait state.
+#define ODEF_TV_DPPCTL " row_mask:0xf bank_mask:0xf\n\t"
+#define ODEF_TV_FB4_COLS(SGN)                                                                          \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_fmac_f64_dpp %0, " SGN "%4, %5 row_newbcast:%6" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %1, " SGN "%4, %5 row_newbcast:%7" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %2, " SGN "%4, %5 row_newbcast:%8" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %3, " SGN "%4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"                    \
+      : "+v"(acc[C0]), "+v"(acc[C0 + 1]), "+v"(acc[C0 + 2]), "+v"(acc[C0 + 3])                         \
+      : "v"(src), "v"(b), "n"(C0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3))
+#define ODEF_TV_FB4_ROWS(SGN)                                                                          \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_fmac_f64_dpp %0, " SGN "%4, %8 row_newbcast:%9" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %1, " SGN "%5, %8 row_newbcast:%9" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %2, " SGN "%6, %8 row_newbcast:%9" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %3, " SGN "%7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"                    \
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                         \
+      : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(b), "n"(K))
+#define ODEF_TV_FB4_DOT(SGN)                                                                           \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_fmac_f64_dpp %0, " SGN "%1, %5 row_newbcast:%9" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %0, " SGN "%2, %6 row_newbcast:%9" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %0, " SGN "%3, %7 row_newbcast:%9" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %0, " SGN "%4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"                    \
+      : "+v"(acc)                                                                                      \
+      : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "n"(K))
+#define ODEF_TV_FB4_LANES(SGN)                                                                         \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_fmac_f64_dpp %0, " SGN "%1, %2 row_newbcast:%6" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %0, " SGN "%1, %3 row_newbcast:%7" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %0, " SGN "%1, %4 row_newbcast:%8" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %0, " SGN "%1, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"                    \
+      : "+v"(acc)                                                                                      \
+      : "v"(src), "v"(b[C0]), "v"(b[C0 + 1]), "v"(b[C0 + 2]), "v"(b[C0 + 3]), "n"(C0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3))
+template <bool NEG, int K>
+ODEF_TV_INLINE void fb1(double& acc, double src, double b) {
+  if constexpr (NEG) fnma_bc<K>(acc, src, b);
+  else fma_bc<K>(acc, src, b);
+}
+template <bool NEG, int C0, int n>
+ODEF_TV_INLINE void fb_cols(double* acc, double src, double b) {
   if constexpr (n >= 4) {
-    asm("s_nop 1\n\t"
-        "v_fmac_f64_dpp %0, -%4, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %1, -%4, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %2, -%4, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %3, -%4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
-        : "+v"(acc[C0]), "+v"(acc[C0 + 1]), "+v"(acc[C0 + 2]), "+v"(acc[C0 + 3])
-        : "v"(src), "v"(b), "n"(C0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3));
-    fnma_bc_cols<C0 + 4, n - 4>(acc, src, b);
+    if constexpr (NEG) ODEF_TV_FB4_COLS("-");
+    else ODEF_TV_FB4_COLS("");
+    fb_cols<NEG, C0 + 4, n - 4>(acc, src, b);
   } else if constexpr (n > 0) {
-    fnma_bc<C0>(acc[C0], src, b);
-    fnma_bc_cols<C0 + 1, n - 1>(acc, src, b);
+    fb1<NEG, C0>(acc[C0], src, b);
+    fb_cols<NEG, C0 + 1, n - 1>(acc, src, b);
   }
+}
+template <bool NEG, int K, int n>
+ODEF_TV_INLINE void fb_rows(double* acc, const double* src, double b) {
+  if constexpr (n >= 4) {
+    if constexpr (NEG) ODEF_TV_FB4_ROWS("-");
+    else ODEF_TV_FB4_ROWS("");
+    fb_rows<NEG, K, n - 4>(acc + 4, src + 4, b);
+  } else if constexpr (n > 0) {
+    fb1<NEG, K>(acc[0], src[0], b);
+    fb_rows<NEG, K, n - 1>(acc + 1, src + 1, b);
+  }
+}
+template <bool NEG, int K, int n>
+ODEF_TV_INLINE void fb_dot(double& acc, const double* src, const double* b) {
+  if constexpr (n >= 4) {
+    if constexpr (NEG) ODEF_TV_FB4_DOT("-");
+    else ODEF_TV_FB4_DOT("");
+    fb_dot<NEG, K, n - 4>(acc, src + 4, b + 4);
+  } else if constexpr (n > 0) {
+    fb1<NEG, K>(acc, src[0], b[0]);
+    fb_dot<NEG, K, n - 1>(acc, src + 1, b + 1);
+  }
+}
+template <bool NEG, int C0, int n>
+ODEF_TV_INLINE void fb_lanes(double& acc, double src, const double* b) {
+  if constexpr (n >= 4) {
+    if constexpr (NEG) ODEF_TV_FB4_LANES("-");
+    else ODEF_TV_FB4_LANES("");
+    fb_lanes<NEG, C0 + 4, n - 4>(acc, src, b);
+  } else if constexpr (n > 0) {
+    fb1<NEG, C0>(acc, src, b[C0]);
+    fb_lanes<NEG, C0 + 1, n - 1>(acc, src, b);
+  }
+}
+template <int C0, int n>
+ODEF_TV_INLINE void fnma_bc_cols(double* acc, double src, double b) { fb_cols<true, C0, n>(acc, src, b); }
+// lane r -> vals[r / d] for r < d * NB, `fill` in the idle lanes
+template <int d, int NB>
+ODEF_TV_INLINE double block_table(const double* vals, double fill) {
+  const int J = lane() / d;
+  double v = fill;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) v = (J == k) ? vals[k] : v;
+  return v;
 }
 template <int S>
 ODEF_TV_INLINE double shl(double x) {  // two 32-bit row shifts (the FP64 ALU has no shifting DPP control); 0 beyond the row
@@ -306,14 +464,14 @@ ODEF_TV_INLINE double shl(double x) {  // two 32-bit row shifts (the FP64 ALU ha
 }
 
 struct Lds {
-  double* p;  // [kLdsRows][LD], this team's slice of the workgroup's LDS
+  double* p;  // [lds_rows][LD], this team's slice of the workgroup's LDS
 };
 ODEF_TV_INLINE void lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
-ODEF_TV_INLINE void lds_clear(const Lds& m, int LD) {
-  for (int k = lane(); k < kLdsRows * LD; k += kTeam) m.p[k] = 0.0;
+ODEF_TV_INLINE void lds_clear(const Lds& m, int doubles) {
+  for (int k = lane(); k < doubles; k += kTeam) m.p[k] = 0.0;
   lds_sync();
 }
 typedef double tv_double2 __attribute__((ext_vector_type(2)));
@@ -370,6 +528,9 @@ ODEF_TV_INLINE double field_load(const Field& f, unsigned off) {
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(f.rs, off, 0, 0));
 }
 ODEF_TV_INLINE void field_store_uniform(const Field& f, unsigned off, double x) { field_store(f, off, x); }
+ODEF_TV_INLINE double field_load_uniform(const Field& f, size_t N, long i, int row) {
+  return field_load(f, (unsigned)(((size_t)row * N + (size_t)i) * sizeof(double)));
+}
 #endif
 
 }  // namespace tv

@@ -12,10 +12,13 @@ import torch.distributed as dist
 
 
 def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous block [lo, hi) of rank `rank`; the first `total % world` ranks get one extra."""
-    base, rem = divmod(total, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    """Contiguous block [lo, hi) of rank `rank`; the first `total % world` ranks get one extra.  The arithmetic is the
+    C ABI's (`odef_shard_range`, include/odefilter.h), so the one-process-per-GPU path here and the single-process
+    `odef_group` a Julia host drives cut an ensemble identically."""
+    from .host import shard_range
+
+    lo, n = shard_range(total, world, rank)
+    return lo, lo + n
 
 
 def init_from_env(backend: str = "nccl") -> Tuple[int, int, int]:

@@ -81,6 +81,21 @@ SYMBOLS = {
     "odef_predict": (C.c_int, [C.c_int, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp]),
     "odef_update": (C.c_int, [C.c_int, C.c_int, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp]),
     "odef_smooth_step": (C.c_int, [C.c_int, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    # ensemble sharded over the GPUs of one node by one process
+    "odef_shard_range": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "odef_group_create": (C.c_int, [C.POINTER(_vp), C.POINTER(OdefConfig), C.c_int32, C.POINTER(C.c_int32)]),
+    "odef_group_destroy": (None, [_vp]),
+    "odef_group_last_error": (C.c_char_p, [_vp]),
+    "odef_group_size": (C.c_int32, [_vp]),
+    "odef_group_ctx": (_vp, [_vp, C.c_int32]),
+    "odef_group_shard": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "odef_group_set_problem": (C.c_int, [_vp, _dp, _dp, C.c_double]),
+    "odef_group_set_problem_perturbed": (C.c_int, [_vp, _dp, _dp, C.c_double, C.c_double, C.c_uint64, C.c_int32]),
+    "odef_group_solve_fixed": (C.c_int, [_vp, _dp, C.c_int64]),
+    "odef_group_solve_adaptive": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(OdefController), C.c_int64]),
+    "odef_group_smooth": (C.c_int, [_vp]),
+    "odef_allgather": (C.c_int, [_vp, C.c_int]),
+    "odef_group_get_gathered": (C.c_int, [_vp, C.c_int32, _dp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
 }
 
 _lib = None
@@ -105,6 +120,94 @@ def load_library() -> C.CDLL:
 
 class OdefError(RuntimeError):
     pass
+
+
+def shard_range(n_traj: int, n_shards: int, shard: int):
+    """(first, count) of a shard: contiguous blocks, the first n_traj % n_shards one longer (`odef_shard_range`; host
+    arithmetic only, works without a GPU)."""
+    first, count = C.c_int64(), C.c_int64()
+    if load_library().odef_shard_range(int(n_traj), int(n_shards), int(shard), C.byref(first), C.byref(count)) != 0:
+        raise OdefError(f"odef_shard_range({n_traj}, {n_shards}, {shard}): invalid arguments")
+    return int(first.value), int(count.value)
+
+
+class DeviceGroup:
+    """`odef_group`: one ensemble sharded over the GPUs of a node by THIS process (what a Julia host binds with ccall,
+    julia/ODEFilterHIP.jl) -- contiguous blocks, no exchange while stepping, `allgather()` = the one RCCL collective."""
+
+    def __init__(self, rhs: str, order: int, alg: int, n_traj: int, n_devices: int, *, device_ids=None, diffusion="dynamic",
+                 smooth=False, save_everystep=True, want_loglik=True):
+        self.lib = load_library()
+        d, npar = RHS_DIMS[rhs]
+        cfg = OdefConfig()
+        cfg.struct_size = C.sizeof(OdefConfig)
+        cfg.alg, cfg.order, cfg.diffusion = alg, order, DIFFUSION[diffusion]
+        cfg.smooth, cfg.rhs_id, cfg.d, cfg.n_params = int(smooth), RHS[rhs], d, npar
+        cfg.params_shared = 1
+        cfg.save_mode = SAVE_EVERYSTEP if (save_everystep or smooth) else SAVE_FINAL
+        cfg.device, cfg.want_loglik, cfg.n_traj = -1, int(want_loglik), n_traj
+        self.d, self.D, self.N, self.G = d, d * (order + 1), n_traj, n_devices
+        ids = (C.c_int32 * n_devices)(*device_ids) if device_ids is not None else None
+        h = _vp()
+        if self.lib.odef_group_create(C.byref(h), C.byref(cfg), n_devices, ids) != 0:
+            raise OdefError(self.lib.odef_group_last_error(None).decode())
+        self._h = h
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise OdefError(self.lib.odef_group_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.odef_group_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def shard(self, g: int):
+        first, count = C.c_int64(), C.c_int64()
+        self._chk(self.lib.odef_group_shard(self._h, g, C.byref(first), C.byref(count)))
+        return int(first.value), int(count.value)
+
+    def set_problem(self, u0, p, t0):
+        u0 = np.ascontiguousarray(u0, dtype=np.float64)
+        pp = _as_dp(np.ascontiguousarray(p, dtype=np.float64)) if p is not None and len(p) else None
+        self._chk(self.lib.odef_group_set_problem(self._h, _as_dp(u0), pp, float(t0)))
+
+    def set_problem_perturbed(self, base_u0, p, t0, scale, seed=0x0DEF17E5, n_perturbed=None):
+        base = np.ascontiguousarray(base_u0, dtype=np.float64)
+        pp = _as_dp(np.ascontiguousarray(p, dtype=np.float64)) if p is not None and len(p) else None
+        self._chk(self.lib.odef_group_set_problem_perturbed(self._h, _as_dp(base), pp, float(t0), float(scale), C.c_uint64(seed),
+                                                            self.d if n_perturbed is None else n_perturbed))
+
+    def solve_fixed(self, tgrid):
+        tg = np.ascontiguousarray(tgrid, dtype=np.float64)
+        self._chk(self.lib.odef_group_solve_fixed(self._h, _as_dp(tg), len(tg)))
+
+    def solve_adaptive(self, t1, abstol=1e-6, reltol=1e-3, dt0=1e-3, max_steps=4096):
+        self._chk(self.lib.odef_group_solve_adaptive(self._h, float(t1), float(abstol), float(reltol), float(dt0), None, int(max_steps)))
+
+    def smooth(self):
+        self._chk(self.lib.odef_group_smooth(self._h))
+
+    def allgather(self, smoothed=False, from_device=0) -> np.ndarray:
+        """Final posterior means of the WHOLE ensemble, [D, N], as device `from_device` holds them after the all-gather."""
+        self._chk(self.lib.odef_allgather(self._h, int(smoothed)))
+        out = np.empty((self.D, self.N))
+        self._chk(self.lib.odef_group_get_gathered(self._h, from_device, _as_dp(out), None, None))
+        return out
+
+    def shard_kernel_ms(self, which=0):
+        ms = []
+        for g in range(self.G):
+            t, n = C.c_float(), C.c_int()
+            self.lib.odef_kernel_time_ms(self.lib.odef_group_ctx(self._h, g), which, C.byref(t), C.byref(n))
+            ms.append(float(t.value))
+        return ms
 
 
 def compile_rhs(name: str, source: str, d: int, n_params: int, struct_name: Optional[str] = None) -> str:

@@ -12,6 +12,7 @@
 #include "../../odefilters.jl_amd/csrc/filter_tiles.h"
 #include "../../odefilters.jl_amd/csrc/sample_lane.h"
 #include "../../odefilters.jl_amd/csrc/rows_filter.h"
+#include "../../odefilters.jl_amd/csrc/rows_smooth.h"
 #include <vector>
 #include <cstring>
 
@@ -63,10 +64,11 @@ struct RunFilter {
       const long i0 = (i / 64) * 64;
       if (P.stagger == 9) {  // row-per-lane team filter (rows_filter.h): one 16-lane team per trajectory
         if constexpr (RHS::d * (q + 1) <= 16) {
-          std::vector<double> ws(tv::kLdsRows * tv::lds_ld(RHS::d * (q + 1)));
-          if (adaptive) rows_filter_adaptive<RHS, q, EK1>(P, i, ws.data());
-          else if (P.everystep) rows_filter_fixed<RHS, q, EK1, true>(P, i, ws.data());
-          else rows_filter_fixed<RHS, q, EK1, false>(P, i, ws.data());
+          std::vector<double> ws(tv::lds_rows(RHS::d, q + 1) * tv::lds_ld(RHS::d * (q + 1)));
+          const RowsTeam tm{i, i, true, 0, ws.data(), nullptr};
+          if (adaptive) rows_filter_adaptive<RHS, q, EK1>(P, tm);
+          else if (P.everystep) rows_filter_fixed<RHS, q, EK1, true>(P, tm);
+          else rows_filter_fixed<RHS, q, EK1, false>(P, tm);
         }
         continue;
       }
@@ -79,8 +81,25 @@ struct RunFilter {
 };
 struct RunSmooth {
   const SmoothParams& P;
+  int bcast_rows = 0;  // the DPP-broadcast row-team smoother (rows_smooth.h) instead of the default for this size
   template <int d, int q>
   void operator()() {
+    if constexpr (d * (q + 1) <= 16) {
+      if (bcast_rows) {
+        std::vector<double> ws(tv::lds_rows(d, q + 1) * tv::lds_ld(d * (q + 1)));
+        for (long i = 0; i < P.N; ++i) {
+          const RowsTeam tm{i, i, true, 0, ws.data(), nullptr};
+          if (P.adaptive) {
+            RowsSmoother<d, q, true> sm;
+            sm.run(P, tm, (long)P.nsaved[i]);
+          } else {
+            RowsSmoother<d, q, false> sm;
+            sm.run(P, tm, P.n_save);
+          }
+        }
+        return;
+      }
+    }
     if constexpr (d * (q + 1) <= 12) {  // lane-per-trajectory smoother, lane-private memory = a plain array here
       constexpr int D = d * (q + 1);
       std::vector<double> x(D * (D + 1) / 2);
@@ -125,7 +144,7 @@ extern "C" int emul_smooth(const EmulArgs* a, int d) {
   P.hs = a->hs; P.ptab = a->ptab; P.tab_idx = a->tab_idx; P.tsave = a->tsave; P.nsaved = a->nsaved;
   P.mean = a->mean; P.cov = a->cov; P.diff = a->diff; P.smean = a->smean; P.scov = a->scov;
   P.retcode = a->retcode;
-  RunSmooth r{P};
+  RunSmooth r{P, a->everystep == 3};
   if (d == 2) return dispatch_smooth_order<2>(a->q, r);
   if (d == 3) return dispatch_smooth_order<3>(a->q, r);
   if (d == 28) return dispatch_smooth_order<28>(a->q, r);

@@ -20,7 +20,7 @@ def declared_symbols():
 def test_header_symbols_all_exported(pkg):
     lib = pkg.load_library()
     names = declared_symbols()
-    assert len(names) == 27
+    assert len(names) == 41  # 27 per-context entry points + 14 of the multi-GPU group (odef_shard_range, odef_group_*, odef_allgather)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/odefilter.h but not exported"
     # and the Python binding table covers exactly the header
@@ -80,3 +80,22 @@ def test_create_argument_validation(pkg):
     cfg.d, cfg.order = 3, 9
     assert lib.odef_create(C.byref(h), C.byref(cfg)) != 0
     assert b"order" in lib.odef_last_error(None)
+
+
+def test_shard_range_arithmetic(pkg):
+    """odef_shard_range (host arithmetic of the multi-GPU group, no GPU needed): contiguous, ordered, complete, the
+    first n % G shards one longer -- the partition SURVEY.md 8(e) prescribes; dist.shard_bounds is the same function."""
+    from odefilters_jl_amd import dist, host
+
+    for n, G in [(65536, 8), (16384, 8), (7, 2), (10, 3), (8, 8), (1000003, 6)]:
+        nxt = 0
+        for g in range(G):
+            first, cnt = host.shard_range(n, G, g)
+            assert first == nxt and cnt in (n // G, n // G + 1) and (cnt == n // G + 1) == (g < n % G)
+            assert dist.shard_bounds(n, g, G) == (first, first + cnt)
+            nxt = first + cnt
+        assert nxt == n
+    with pytest.raises(host.OdefError):
+        host.shard_range(10, 3, 3)
+    with pytest.raises(host.OdefError):
+        host.shard_range(10, 0, 0)

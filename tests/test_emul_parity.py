@@ -321,3 +321,54 @@ def test_row_team_filter_static_diffusion(model):
     np.testing.assert_allclose(final, sol.diffusions[-1], rtol=1e-9)
     np.testing.assert_allclose(r["mean"][0][:, :2], sol.means()[:, :2], rtol=1e-10)
     assert P.cov_err(r["cov"][0] * final, sol.covs()) < 1e-7
+
+
+@pytest.mark.parametrize("rhs,order,t1", [("lorenz63", 3, 0.5), ("fhn", 2, 2.0), ("vanderpol", 4, 0.3)])
+def test_row_team_adaptive_filter_and_smoother(rhs, order, t1):
+    """rows_filter.h / rows_smooth.h, adaptive: the PI-controller loop of a 16-lane team (one record per ATTEMPTED step,
+    rejected attempts repeat the old state) and the backward pass over those records, against the oracle's
+    OrdinaryDiffEq restatement -- same accepted / rejected step sequence, posterior at the oracle's noise level."""
+    vf = orc.vector_field(rhs)
+    alg = orc.EK1(order=order, smooth=True)
+    sol = orc.solve(vf, alg, adaptive=True, dt=2.0**-9, tspan=(0.0, t1))
+    u0s = np.stack([vf.u0, vf.u0 * (1 + 1e-3)])
+    r = E.emul_solve(vf.rhs_id, vf.d, order, True, u0s, vf.p, adaptive=True, t0=0.0, t1=t1, dt0=2.0**-9, max_save=1024,
+                     smooth=True, everystep=3)
+    n = r["nsaved"][0]
+    assert n == len(sol.t) and r["nreject"][0] == sol.nreject and r["retcode"][0] == 0
+    assert r["nsaved_raw"][0] == sol.naccept + sol.nreject + 1  # one record per attempt
+    # (stiff van der Pol at order 4: the error estimate itself carries the 1e-8 noise of the higher derivatives, _parity.py)
+    rt = 1e-6 if rhs == "vanderpol" else 1e-9
+    np.testing.assert_allclose(r["tsave"][0][:n], sol.t, rtol=rt)
+    np.testing.assert_allclose(r["mean"][0][:n, :vf.d], sol.means(smoothed=False)[:, :vf.d], rtol=100 * rt)
+    np.testing.assert_allclose(r["smean"][0][:n, :vf.d], sol.means(smoothed=True)[:, :vf.d], rtol=100 * rt)
+    np.testing.assert_allclose(r["diff"][0][1:n], sol.diffusions, rtol=1e-4)
+    np.testing.assert_allclose(r["loglik"][0], sol.log_likelihood, rtol=1e-6)
+    assert P.cov_err(r["scov"][0][:n], sol.covs(smoothed=True)) < 1e-5
+    # the lane kernels on the same problem: same step sequence, same posterior to rounding
+    l = E.emul_solve(vf.rhs_id, vf.d, order, True, u0s, vf.p, adaptive=True, t0=0.0, t1=t1, dt0=2.0**-9, max_save=1024, smooth=True)
+    assert (l["nsaved"] == r["nsaved"]).all() and (l["nreject"] == r["nreject"]).all()
+    np.testing.assert_allclose(r["smean"][1][: r["nsaved"][1], :vf.d], l["smean"][1][: l["nsaved"][1], :vf.d], rtol=100 * rt)
+
+
+def test_row_team_adaptive_rejections_and_limits():
+    """A first step that is far too long is rejected (the record repeats the initial state at t0); a record budget that is
+    too small ends in MaxIters with what was saved; static diffusion rides along."""
+    vf = orc.vector_field("lorenz63")
+    alg = orc.EK1(order=3, smooth=True)
+    sol = orc.solve(vf, alg, adaptive=True, dt=0.25, tspan=(0.0, 0.5))
+    assert sol.nreject >= 1
+    r = E.emul_solve(vf.rhs_id, 3, 3, True, vf.u0[None, :], vf.p, adaptive=True, t0=0.0, t1=0.5, dt0=0.25, max_save=512,
+                     smooth=True, everystep=3)
+    n = r["nsaved"][0]
+    assert n == len(sol.t) and r["nreject"][0] == sol.nreject and r["naccept"][0] == sol.naccept
+    np.testing.assert_allclose(r["smean"][0][:n, :3], sol.means(smoothed=True)[:, :3], rtol=1e-7)
+    short = E.emul_solve(vf.rhs_id, 3, 3, True, vf.u0[None, :], vf.p, adaptive=True, t0=0.0, t1=0.5, dt0=2.0**-9, max_save=8,
+                         everystep=3)
+    assert short["retcode"][0] == 1 and short["nsaved_raw"][0] == 8
+    fx = orc.solve(vf, orc.EK1(order=3, diffusionmodel="fixed", smooth=False), adaptive=True, dt=2.0**-9, tspan=(0.0, 0.25))
+    rf = E.emul_solve(vf.rhs_id, 3, 3, True, vf.u0[None, :], vf.p, adaptive=True, t0=0.0, t1=0.25, dt0=2.0**-9, max_save=512,
+                      everystep=3, fixed_diffusion=1)
+    nf = rf["nsaved"][0]
+    assert nf == len(fx.t)
+    np.testing.assert_allclose(rf["mean"][0][:nf, :3], fx.means(smoothed=False)[:, :3], rtol=1e-7)

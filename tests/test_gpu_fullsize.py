@@ -1,0 +1,146 @@
+"""BASELINE.json configurations 2-5 at their FULL sizes on the GPU: size-independent properties over the whole ensemble
+plus, for a handful of trajectories, value-by-value comparison with oracle fixtures computed at the full step count
+(tests/golden/full_*.npz, generator tests/golden/make_fullsize.py).  The kernels a configuration gets by default are the
+ones under test (row-team kernels for configs 2 and 5, the lane kernel for config 3, the tiled kernel for config 4).
+
+Tolerances: solution components u = E0 mu at 1e-10 relative (BASELINE target 1e-8); the derivative blocks and the
+covariances are ill-conditioned in the reference's own arithmetic (tests/_parity.py) and are compared at the level the
+float64 oracle itself reproduces under 1-ulp input changes (1e-6 of the block scale, 5e-3 of the covariance scale at the
+transient near t = 1.15, tests/golden/exact_lorenz_mp.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+import _parity as P
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LORENZ_U0, LORENZ_P = [1.0, 0.0, 0.0], [10.0, 28.0, 8.0 / 3.0]
+
+
+def _block_tol_check(got, ref, d, what):
+    be = P.block_err(got, ref, d)
+    assert be[0] <= 1e-10, f"{what}: u block off by {be[0]:.2e}"
+    assert np.all(be[1:] <= 1e-6), f"{what}: derivative blocks off by {be}"
+
+
+def test_config2_lorenz_4096_filter_and_smoother(pkg):
+    """configs[1]: Lorenz-63 EK1(3), 4 096 trajectories x 1 024 steps, every step saved, RTS smoother."""
+    fx = np.load(os.path.join(GOLD, "full_lorenz_fixed.npz"))
+    N, ns, dt = 4096, int(fx["nsteps"]), float(fx["dt"])
+    ctx = pkg.Context("lorenz63", 3, 1, N, smooth=True)
+    ctx.set_problem_perturbed(LORENZ_U0, LORENZ_P, 0.0, 1e-2)
+    ctx.solve_fixed(np.arange(ns + 1) * dt)
+    ctx.smooth()
+    assert (ctx.get(10) == 0).all() and (ctx.get(9) == ns + 1).all()
+    mean, smean = ctx.get(0), ctx.get(11)  # [n_save, D, N]
+    cov, scov = ctx.get(1), ctx.get(12)
+    assert np.isfinite(mean).all() and np.isfinite(smean).all() and np.isfinite(cov).all() and np.isfinite(scov).all()
+    assert np.all(cov[0] == 0.0) and np.all(scov[0] == 0.0)  # x0 is exact (test/solution.jl:38-41)
+    np.testing.assert_array_equal(smean[-1], mean[-1])  # the last smoothed state is the last filter state (test/smoothing.jl)
+    np.testing.assert_array_equal(scov[-1], cov[-1])
+    # PSD over the whole ensemble at three times (filter and smoothed), variances decrease under smoothing
+    for s in (1, 512, ns):
+        for c in (cov, scov):
+            w = np.linalg.eigvalsh(pkg.unpack_tril(c[s].T, 12))
+            assert w.min() > -1e-9 * np.abs(w).max()
+    diag = [k * (k + 1) // 2 + k for k in range(12)]
+    assert np.all(scov[1:ns][:, diag] <= cov[1:ns][:, diag] * (1 + 1e-9) + 1e-300)
+    steps = fx["steps"]
+    for k, gi in enumerate(fx["idx"]):
+        if gi >= N:
+            continue
+        _block_tol_check(mean[steps][:, :, gi], fx["mean_filt"][k], 3, f"config 2 filter, trajectory {gi}")
+        _block_tol_check(smean[steps][:, :, gi], fx["mean_smooth"][k], 3, f"config 2 smoother, trajectory {gi}")
+        assert P.cov_err(pkg.unpack_tril(cov[steps][:, :, gi], 12), fx["cov_filt"][k]) < 5e-3
+        assert P.cov_err(pkg.unpack_tril(scov[steps][:, :, gi], 12), fx["cov_smooth"][k]) < 5e-3
+        # sigma^2 = z' W^-1 z / d is a squared RESIDUAL: it inherits the noise of the highest derivative twice over
+        np.testing.assert_allclose(ctx.get(2)[1:, gi], fx["diffusions"][k], rtol=2e-3)
+        np.testing.assert_allclose(ctx.get(4)[gi], fx["loglik"][k], rtol=1e-6)
+    # final-only save mode = the last every-step record, bit for bit
+    ctx2 = pkg.Context("lorenz63", 3, 1, N, save_everystep=False)
+    ctx2.set_problem_perturbed(LORENZ_U0, LORENZ_P, 0.0, 1e-2)
+    ctx2.solve_fixed(np.arange(ns + 1) * dt)
+    np.testing.assert_array_equal(ctx2.get(0)[0], mean[-1])
+    np.testing.assert_array_equal(ctx2.get(1)[0], cov[-1])
+    ctx.close()
+    ctx2.close()
+
+
+def test_config3_lorenz_65536_final_state(pkg):
+    """configs[2]: 65 536 trajectories x 1 024 steps (final-save mode here: the every-step record of this size is
+    48.9 GB and is what bench.py times and checks); duplicated inputs give bitwise equal outputs."""
+    fx = np.load(os.path.join(GOLD, "full_lorenz_fixed.npz"))
+    N, ns, dt = 65536, int(fx["nsteps"]), float(fx["dt"])
+    ctx = pkg.Context("lorenz63", 3, 1, N, save_everystep=False)
+    ctx.set_problem_perturbed(LORENZ_U0, LORENZ_P, 0.0, 1e-2)
+    ctx.solve_fixed(np.arange(ns + 1) * dt)
+    assert (ctx.get(10) == 0).all()
+    mean, cov = ctx.get(0)[0], ctx.get(1)[0]
+    assert np.isfinite(mean).all() and np.isfinite(cov).all()
+    for k, gi in enumerate(fx["idx"]):
+        _block_tol_check(mean[None, :, gi], fx["mean_filt"][k][-1:], 3, f"config 3, trajectory {gi}")
+        assert P.cov_err(pkg.unpack_tril(cov[None, :, gi], 12), fx["cov_filt"][k][-1:]) < 5e-3
+    w = np.linalg.eigvalsh(pkg.unpack_tril(cov[:, ::64].T, 12))
+    assert w.min() > -1e-9 * np.abs(w).max()
+    # the 8-GPU shard of the same ensemble (8 192 trajectories, row-team kernel): same trajectories to rounding
+    ctx8 = pkg.Context("lorenz63", 3, 1, 8192, save_everystep=False)
+    ctx8.set_problem_perturbed(LORENZ_U0, LORENZ_P, 0.0, 1e-2)
+    ctx8.solve_fixed(np.arange(ns + 1) * dt)
+    np.testing.assert_allclose(ctx8.get(0)[0][:3], mean[:3, :8192], rtol=1e-10)
+    ctx.close()
+    ctx8.close()
+
+
+def test_config4_pleiades_8192_final_state(pkg):
+    """configs[3]: Pleiades d = 28, EK1(5) (state dimension 168), 8 192 trajectories x 256 steps, final state."""
+    fx = np.load(os.path.join(GOLD, "full_pleiades.npz"))
+    N, ns, dt = 8192, int(fx["nsteps"]), float(fx["dt"])
+    base = np.array([3, 3, -1, -3, 2, -2, 2, 3, -3, 2, 0, 0, -4, 4, 0, 0, 0, 0, 0, 1.75, -1.5, 0, 0, 0, -1.25, 1, 0, 0], float)
+    ctx = pkg.Context("pleiades", 5, 1, N, save_everystep=False)
+    ctx.set_problem_perturbed(base, [], 0.0, 1e-3, n_perturbed=14)
+    ctx.solve_fixed(np.arange(ns + 1) * dt)
+    assert (ctx.get(10) == 0).all()
+    mean, cov = ctx.get(0)[0], ctx.get(1)[0]
+    assert np.isfinite(mean).all() and np.isfinite(cov).all()
+    diag = np.array([k * (k + 1) // 2 + k for k in range(168)])
+    assert (cov[diag] >= 0).all()
+    for k, gi in enumerate(fx["idx"]):
+        np.testing.assert_allclose(ctx.get(13)[:, gi], fx["u0s"][k], rtol=0, atol=0)  # same ensemble as the fixture's
+        np.testing.assert_allclose(mean[:28, gi], fx["u_final"][k], rtol=1e-10)
+        be = P.block_err(mean[None, :, gi], fx["mean_final"][k][None], 28)
+        assert be[0] <= 1e-10 and np.all(be[1:4] <= 1e-6), be
+        np.testing.assert_allclose(cov[diag[:56], gi], fx["var_final"][k][:56], rtol=1e-4)
+    ctx.close()
+
+
+def test_config5_lorenz_16384_adaptive_and_smoother(pkg):
+    """configs[4]: Lorenz-63 EK1(3), 16 384 trajectories, adaptive PI step-size control + RTS smoothing."""
+    fx = np.load(os.path.join(GOLD, "full_lorenz_adaptive.npz"))
+    N = 16384
+    ctx = pkg.Context("lorenz63", 3, 1, N, smooth=True)
+    ctx.set_problem_perturbed(LORENZ_U0, LORENZ_P, 0.0, 1e-2)
+    ctx.solve_adaptive(2.0, 1e-6, 1e-3, 2.0**-9, max_steps=400)
+    ctx.smooth()
+    ret, nsaved, nacc, nrej = ctx.get(10), ctx.get(9), ctx.get(5), ctx.get(6)
+    assert (ret == 0).all() and (nsaved == nacc + nrej + 1).all() and nsaved.max() <= 401
+    T, mean, smean, scov = ctx.get(3), ctx.get(0), ctx.get(11), ctx.get(12)
+    last = nsaved - 1
+    cols = np.arange(N)
+    assert np.all(T[last, cols] == 2.0) and np.all(T[0] == 0.0)
+    assert np.all(np.diff(T, axis=0)[: nsaved.min() - 1] >= 0)
+    np.testing.assert_array_equal(smean[last, :, cols], mean[last, :, cols])  # last smoothed = last filter state
+    assert np.isfinite(smean[0]).all() and np.isfinite(scov[1]).all()
+    for k, gi in enumerate(fx["idx"]):
+        n = nsaved[gi]
+        t = T[:n, gi]
+        keep = np.concatenate([[True], t[1:] != t[:-1]])  # drop the repeated records of rejected attempts
+        tt, mf, msm = t[keep], mean[:n, :, gi][keep], smean[:n, :, gi][keep]
+        assert (nacc[gi], nrej[gi]) == tuple(fx[f"counts{k}"]), f"trajectory {gi}: accepted/rejected differ from the oracle"
+        np.testing.assert_allclose(tt, fx[f"t{k}"], rtol=1e-9)
+        np.testing.assert_allclose(mf[:, :3], fx[f"mean_filt{k}"][:, :3], rtol=1e-7)
+        np.testing.assert_allclose(msm[:, :3], fx[f"mean_smooth{k}"][:, :3], rtol=1e-7)
+        var = scov[:n, :, gi][keep][:, [0, 2, 5]]
+        np.testing.assert_allclose(var[1:], fx[f"var_smooth{k}"][1:, :3], rtol=1e-3)
+    ctx.close()

@@ -227,11 +227,12 @@ def test_empty_batch_and_bad_dims(pkg):
 # ---- BASELINE-size runs: size-independent properties ------------------------------------------
 
 
-def test_full_size_properties(pkg):
+def test_full_size_properties(pkg, monkeypatch):
     """65 536 trajectories (BASELINE config 3 ensemble), shortened time span so the output fits a
     test: (a) a sample of trajectories matches the oracle, (b) duplicated inputs give bitwise equal
-    outputs wherever they sit in the batch, (c) covariances are PSD with exact zero initial block,
-    (d) final-only save mode equals the last every-step record."""
+    outputs wherever they sit in the batch (same kernel; the row-team kernel a small ensemble gets by default agrees to
+    rounding), (c) covariances are PSD with exact zero initial block, (d) final-only save mode equals the last
+    every-step record."""
     vf = orc.vector_field("lorenz63")
     N, nsteps, dt = 65536, 32, 2.0**-9
     tspan = (0.0, nsteps * dt)
@@ -252,9 +253,13 @@ def test_full_size_properties(pkg):
     pick = np.array([5, 70, 4097, 65535])
     u0_dev = sol.ctx.get(13).T
     prob2 = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, tspan, vf.p), u0s=u0_dev[pick][::-1].copy())
+    monkeypatch.setenv("ODEF_FILTER_ROWS_MAX_N", "0")  # the lane kernel, as for the 65 536
     sol2 = pkg.solve(prob2, pkg.EK1(order=3, smooth=False), pkg.EnsembleHIP(), dt=dt, adaptive=False)
     np.testing.assert_array_equal(sol2.ctx.get(0)[:, :, ::-1], mean[:, :, pick])
     np.testing.assert_array_equal(sol2.ctx.get(1)[:, :, ::-1], cov[:, :, pick])
+    monkeypatch.delenv("ODEF_FILTER_ROWS_MAX_N")  # default: 4 trajectories go to the row-team kernel
+    sol2r = pkg.solve(prob2, pkg.EK1(order=3, smooth=False), pkg.EnsembleHIP(), dt=dt, adaptive=False)
+    np.testing.assert_allclose(sol2r.ctx.get(0)[:, :3, ::-1], mean[:, :3, pick], rtol=1e-11)
     # (d) final-only
     sol3 = pkg.solve(ens, pkg.EK1(order=3, smooth=False), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False,
                      save_everystep=False)
@@ -664,9 +669,13 @@ def _l96_field():
     return orc.VectorField("l96", 100, 4, 1, f, jac, np.array([1.0, 2.0, 0.5, -1.0]), np.array([8.0]), (0.0, 0.25))
 
 
-def test_user_vector_field_equals_the_compiled_in_one(pkg):
+def test_user_vector_field_equals_the_compiled_in_one(pkg, monkeypatch):
     """The same Lorenz-63 text through odef_rhs_compile (hipcc child process) and through the compiled-in registry: identical
-    kernels source, so identical results -- fixed grid + smoother, adaptive, dense output, sampling."""
+    kernels source, so identical results -- fixed grid + smoother, adaptive, dense output, sampling.  (Run-time compiled
+    fields get the lane kernels; the compiled-in side is pinned to them too -- by default 70 trajectories would go to the
+    row-team kernels, which agree to rounding only.)"""
+    monkeypatch.setenv("ODEF_FILTER_ROWS_MAX_N", "0")
+    monkeypatch.setenv("ODEF_SMOOTH_ROWS_MAX_N", "0")
     pkg.compile_rhs("UserLorenz", USER_LORENZ, 3, 3)
     vf = orc.vector_field("lorenz63")
     N = 70
@@ -899,3 +908,71 @@ def test_adaptive_max_steps_reports_maxiters(pkg):
     prob = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, (0.0, 2.0), vf.p), u0s=np.tile(vf.u0, (3, 1)))
     sol = pkg.solve(prob, pkg.EK1(order=3, smooth=False), pkg.EnsembleHIP(), dt=2.0**-9, adaptive=True, max_steps=16)
     assert sol.retcode == ["MaxIters"] * 3 and np.all(sol.ctx.get(9) == 17) and np.all(sol.nsaved <= 17)
+
+
+# ---- multi-GPU group of the C ABI (odef_group_*, odef_allgather) ---------------------------------------------------
+
+
+def test_group_one_device_allgather_through_rccl(pkg):
+    """The single-process multi-GPU entry points with ONE device: shard = whole ensemble, odef_allgather goes through
+    ncclCommInitAll / ncclAllGather (librccl, world of one) and returns the final posterior means a plain context gives."""
+    from odefilters_jl_amd import host
+
+    vf = orc.vector_field("lorenz63")
+    N, ns, dt = 1000, 48, 2.0**-9
+    tg = np.arange(ns + 1) * dt
+    with host.DeviceGroup("lorenz63", 3, 1, N, 1, smooth=True) as grp:
+        assert grp.shard(0) == (0, N)
+        grp.set_problem_perturbed(vf.u0, vf.p, 0.0, 1e-2)
+        grp.solve_fixed(tg)
+        grp.smooth()
+        fin = grp.allgather(smoothed=False)
+        fin_s = grp.allgather(smoothed=True)
+    ctx = pkg.Context("lorenz63", 3, 1, N, smooth=True)
+    ctx.set_problem_perturbed(vf.u0, vf.p, 0.0, 1e-2)
+    ctx.solve_fixed(tg)
+    ctx.smooth()
+    np.testing.assert_array_equal(fin, ctx.get(0)[-1])
+    np.testing.assert_array_equal(fin_s, ctx.get(11)[-1])  # the last smoothed state is the last filter state
+    ctx.close()
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_group_two_shards_equal_one_solve(pkg, adaptive):
+    """Two shards (both on this machine's one GPU: the gather falls back to device copies, the sharding, the concurrent
+    launches and the packing of the final records are the multi-GPU code) against ONE solve of the whole ensemble: an
+    uneven split (1 001 = 501 + 500), global trajectory numbering, fixed and adaptive (record NSAVED-1 per trajectory)."""
+    from odefilters_jl_amd import host
+
+    vf = orc.vector_field("lorenz63")
+    N = 1001
+    with host.DeviceGroup("lorenz63", 3, 1, N, 2, device_ids=[0, 0]) as grp:
+        assert grp.shard(0) == (0, 501) and grp.shard(1) == (501, 500)
+        grp.set_problem_perturbed(vf.u0, vf.p, 0.0, 1e-2)
+        if adaptive:
+            grp.solve_adaptive(0.25, dt0=2.0**-9, max_steps=256)
+        else:
+            grp.solve_fixed(np.arange(33) * 2.0**-9)
+        fin0 = grp.allgather(from_device=0)
+        fin1 = grp.allgather(from_device=1)
+    np.testing.assert_array_equal(fin0, fin1)
+    ctx = pkg.Context("lorenz63", 3, 1, N)
+    ctx.set_problem_perturbed(vf.u0, vf.p, 0.0, 1e-2)
+    if adaptive:
+        ctx.solve_adaptive(0.25, dt0=2.0**-9, max_steps=256)
+        mean, ns = ctx.get(0), ctx.get(9)
+        ref = np.stack([mean[ns[i] - 1, :, i] for i in range(N)], axis=1)
+    else:
+        ctx.solve_fixed(np.arange(33) * 2.0**-9)
+        ref = ctx.get(0)[-1]
+    np.testing.assert_array_equal(fin0, ref)
+    ctx.close()
+    # explicit u0 through the group: every shard takes its block
+    u0s = orc.ensemble_u0(vf.u0, 9, 1e-2)
+    with host.DeviceGroup("lorenz63", 3, 1, 9, 2, device_ids=[0, 0]) as grp:
+        grp.set_problem(u0s, vf.p, 0.0)
+        grp.solve_fixed(np.arange(9) * 2.0**-9)
+        fin = grp.allgather()
+    for i in (0, 4, 5, 8):
+        r = orc.solve(vf, orc.EK1(order=3, smooth=False), u0=u0s[i], tspan=(0.0, 8 * 2.0**-9), dt=2.0**-9)
+        np.testing.assert_allclose(fin[:3, i], r.u[-1], rtol=1e-11)
