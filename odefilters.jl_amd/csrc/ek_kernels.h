@@ -76,9 +76,10 @@ __global__ __launch_bounds__(kRowsBlock) void ek_filter_rows_kernel(const Filter
 }
 template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kRowsBlock) void ek_filter_rows_adaptive_kernel(const FilterParams P) {
-  using L = RowsLds<RHS::d, q + 1, RowsSink<RHS::d*(q + 1), true, true>::kStageDoubles>;
-  __shared__ __attribute__((aligned(16))) double lds[L::size];
-  const RowsTeam tm = rows_team(P.N, lds, L::team);
+  using S = RowsStep<RHS, q, EK1>;
+  constexpr int kStage = RowsSink<S::D, true, true>::kStageDoubles;
+  __shared__ __attribute__((aligned(16))) double lds[kRowsWgTeams * S::kLdsDoublesAdaptive + kStage];
+  const RowsTeam tm = rows_team(P.N, lds, S::kLdsDoublesAdaptive);
   if (tm.i16 < P.N) rows_filter_adaptive<RHS, q, EK1>(P, tm);
 }
 template <class RHS, int q, bool EK1>
@@ -121,17 +122,21 @@ inline long smooth_lane_min_n() {
 // Smoother on DPP broadcasts (rows_smooth.h), 16 lanes per trajectory, D <= 16: small and sharded ensembles.
 // ODEF_SMOOTH_ROWS_MAX_N overrides the crossover (read at every launch); which of the three smoothers runs for D <= 12:
 //   N < kSmoothRowsMaxN: this kernel;  otherwise the lane kernel (N >= kSmoothLaneMinN) or the LDS row teams.
-constexpr long kSmoothRowsMaxN = 40960;
+#ifndef ODEF_ROWS_SMOOTH_WAVES
+#define ODEF_ROWS_SMOOTH_WAVES 2  // waves per SIMD the smoother is compiled for (<= 256 registers)
+#endif
+constexpr long kSmoothRowsMaxN = 49152;
 inline long smooth_rows_max_n() {
   const char* e = getenv("ODEF_SMOOTH_ROWS_MAX_N");
   return e ? atol(e) : kSmoothRowsMaxN;
 }
 template <int d, int q, bool ADAPT>
 __global__ __launch_bounds__(kRowsBlock) void rts_smooth_bcast_kernel(const SmoothParams P) {
-  using L = RowsLds<d, q + 1, RowsSink<d*(q + 1), false, false>::kStageDoubles>;
-  __shared__ __attribute__((aligned(16))) double lds[L::size];
+  using SM = RowsSmoother<d, q, ADAPT>;
+  constexpr int kStage = RowsSink<d*(q + 1), false, false>::kStageDoubles;
+  __shared__ __attribute__((aligned(16))) double lds[kRowsWgTeams * SM::kLdsDoubles + kStage];
   __shared__ int wg_n_hi;
-  const RowsTeam tm = rows_team(P.N, lds, L::team);
+  const RowsTeam tm = rows_team(P.N, lds, SM::kLdsDoubles);
   if (tm.i16 >= P.N) return;  // workgroup-uniform
   long n_hi = P.n_save;
   if constexpr (ADAPT) {  // largest record count among the workgroup's trajectories

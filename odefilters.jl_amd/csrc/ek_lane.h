@@ -281,7 +281,7 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
 #pragma unroll
   for (int a = 0; a < d; ++a) ucur[a] = u0[a];
   const Controller& ct = P.ctrl;
-  double t = P.t0, h = P.dt0, qold = ct.qoldinit, q11 = 1.0;
+  double t = P.t0, h = P.dt0, qold = ct.qoldinit, q11 = 1.0, log_qold = log(ct.qoldinit), log_eest = 0.0;
   double loglik = 0.0, gdiff = 0.0;
   int naccept = 0, nreject = 0, nsaved = 1, ret = 0;
   const long max_attempts = 20 * P.max_save + 1000;
@@ -293,7 +293,7 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
     h = fmin(h, P.t1 - t);  // tstop clipping
     if (!(h > ct.dtmin)) { ret = 2; break; }  // DtLessThanMin
     double tabv[kTabStride];
-    precond_fill<NB>(h, precond_val<q>(h), tabv);
+    precond_table_fast<q, NB, true>(h, tabv);  // no division, no libm pow: rebuilt at every attempted step
     const LocalTab tab{tabv};
     double es[d];
     StepAux aux;
@@ -311,10 +311,10 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
     double acc = 0.0;
 #pragma unroll
     for (int r = 0; r < d; ++r) {
-      const double e = h * es[r] / (P.abstol + fmax(fabs(ucur[r]), fabs(m[r])) * P.reltol);
+      const double e = h * es[r] * rcp_pos(P.abstol + fmax(fabs(ucur[r]), fabs(m[r])) * P.reltol);
       acc += e * e;
     }
-    double EEst = sqrt(acc / d);
+    double EEst = sqrt(acc * (1.0 / d));
     if (!(EEst == EEst) || !(fabs(EEst) <= 1.79769313486231570815e+308)) EEst = INFINITY;
 #pragma unroll
     for (int r = 0; r < d; ++r) ucur[r] = m[r];  // integ.u .= u_filt (src/perform_step.jl:86), also when rejected
@@ -323,9 +323,10 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
     if (EEst == 0.0) {
       qq = 1.0 / ct.qmax;
     } else {
-      // x^b = exp(b log x) for the positive arguments of the controller: 1e-15 relative, a third of pow()'s instructions
-      q11 = exp(ct.beta1 * log(EEst));
-      qq = q11 * exp(-ct.beta2 * log(qold));
+      // x^b = exp(b log x) for the positive arguments of the controller (1e-15 relative, a third of pow()'s
+      // instructions); log(qold) is carried from the attempt that set qold, q11 alone is needed only after a rejection
+      log_eest = log(EEst);
+      qq = exp(ct.beta1 * log_eest - ct.beta2 * log_qold);
       qq = fmax(1.0 / ct.qmax, fmin(1.0 / ct.qmin, qq / ct.gamma));
     }
     const bool accepted = EEst <= 1.0;  // OrdinaryDiffEq accepts on <=
@@ -339,6 +340,7 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
       if (EEst < 1.0) loglik += aux.loglik;
       if (qq <= ct.qsteady_max && qq >= ct.qsteady_min) qq = 1.0;
       qold = fmax(EEst, ct.qoldinit);
+      log_qold = (EEst > ct.qoldinit) ? log_eest : log(ct.qoldinit);
       double tn = t + h;
       if (fabs(tn - P.t1) < 100.0 * 2.220446049250313e-16 * fmax(fabs(tn), fabs(P.t1))) tn = P.t1;
       t = tn;
@@ -347,6 +349,7 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
       h = h / qq;
     } else {
       ++nreject;
+      q11 = (EEst == 0.0) ? 1.0 : exp(ct.beta1 * log_eest);
       h = h / fmin(1.0 / ct.qmin, q11 / ct.gamma);
     }
     // accepted: the new state at the new time; rejected: the old state again at the old time

@@ -57,12 +57,26 @@ struct StepAux {
 // sqrt(x) and 1 / sqrt(x) together, for x > 0: v_rsq_f64 seed and two coupled Goldschmidt steps plus one residual correction each -- 14 instructions where a
 // correctly rounded sqrt followed by a correctly rounded division takes 28 (the pivots of the three factorisations of a
 // step are 12 such pairs, a tenth of its instructions).  Both results within an ulp (tools/rsqrt_accuracy.hip).
+// x = 0 gives NaN (0 * inf in the first product), like any negative x: callers guard their pivots (x > 0) -- the
+// Cholesky columns always did, the reflector norms and chol_small do since round 2.
 __device__ inline void sqrt_and_rsqrt(double x, double& s, double& rs) {
 #ifdef ODEF_HOST_EMUL
-  s = sqrt(x);
-  rs = 1.0 / s;
+  // the device sequence itself, run on the host: the seed is 1/sqrt(x) cut to the 24 bits a v_rsq_f64 seed is good for,
+  // the refinement is the same chain of fused multiply-adds, so tests/emul and the CPU sanitizers execute the arithmetic
+  // the GPU executes (incl. x = 0 -> NaN)
+  double y0;
+  if (x == 0.0) {
+    y0 = INFINITY;
+  } else if (!(x > 0.0) || !(x <= 1.79769313486231570815e+308)) {
+    y0 = (x > 0.0) ? 0.0 : NAN;
+  } else {
+    int e;
+    const double mnt = std::frexp(1.0 / std::sqrt(x), &e);
+    y0 = std::ldexp(std::nearbyint(std::ldexp(mnt, 24)), e - 24);
+  }
 #else
   const double y0 = __builtin_amdgcn_rsq(x);
+#endif
   double g = x * y0;
   double h = 0.5 * y0;
   double r = __builtin_fma(-g, h, 0.5);
@@ -78,7 +92,6 @@ __device__ inline void sqrt_and_rsqrt(double x, double& s, double& rs) {
   y = __builtin_fma(e, y, y);
   s = g;
   rs = y;
-#endif
 }
 
 // In-place Cholesky of a packed symmetric matrix (lower).  A non-positive pivot means the
@@ -204,6 +217,51 @@ __host__ __device__ inline void precond_fill(double h, double pval, double* tab)
     }
 }
 
+// 1 / x for a positive normal x: v_rcp_f64 seed and two Newton steps (5 instructions; libm's division is 10+)
+__device__ inline double rcp_pos(double x) {
+#ifdef ODEF_HOST_EMUL
+  return 1.0 / x;
+#else
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  return y;
+#endif
+}
+
+// P(h) = diag(h^(j-q-1/2)) and its inverse for a step size that differs from trajectory to trajectory (adaptive steps;
+// src/preconditioning.jl:1-17): running products from h^(-q-1/2) like the reference's, the reciprocals as a second
+// running product (inv(::Diagonal) to within an ulp) -- no division, no libm pow: the table is rebuilt by all 16 lanes
+// of a team at every attempted step.
+template <int q, int NB, bool WITH_PRODUCTS = false>
+__device__ inline void precond_table_fast(double h, double* tab) {
+  double hq = 1.0;
+#pragma unroll
+  for (int k = 0; k < q; ++k) hq *= h;
+  double sh, rsh;
+  sqrt_and_rsqrt(h, sh, rsh);
+  double val = rsh * rcp_pos(hq), ival = hq * sh;
+  const double rh = rcp_pos(h);
+#pragma unroll
+  for (int J = 0; J < NB; ++J) {
+    tab[kTabPJ + J] = val;
+    tab[kTabPIJ + J] = ival;
+    val *= h;
+    ival *= rh;
+  }
+  if constexpr (WITH_PRODUCTS) {
+#pragma unroll
+    for (int J = 0; J < NB; ++J)
+#pragma unroll
+      for (int K = 0; K < NB; ++K) {
+        tab[kTabPP + J * MAXNB + K] = tab[kTabPJ + J] * tab[kTabPJ + K];
+        tab[kTabPIPI + J * MAXNB + K] = tab[kTabPIJ + J] * tab[kTabPIJ + K];
+      }
+  }
+}
+
 // X <- A X A' + sigma2 * Q  in place on packed symmetric storage, A = At (x) I_d block upper
 // triangular: the Gram matrix of `_L = [A*L  sqrt(sigma2)*Q_L]` (src/filtering.jl:34-35).
 // A = E_{NB-2} ... E_1 E_0 with E_J = I + sum_{j>J} At[J][j] e_J e_j' (block row J picks up the
@@ -271,8 +329,11 @@ __device__ inline void chol_small(const double (&S)[n][n], double (&L)[n][n], do
     double s = S[j][j];
 #pragma unroll
     for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+    const bool ok = s > 0.0;  // a non-positive pivot zeroes its column (the semi-definite rule of chol_packed)
     double ljj, inv;
-    sqrt_and_rsqrt(s, ljj, inv);
+    sqrt_and_rsqrt(ok ? s : 1.0, ljj, inv);
+    ljj = ok ? ljj : 0.0;
+    inv = ok ? inv : 0.0;
     L[j][j] = ljj;
     Ldinv[j] = inv;
 #pragma unroll
@@ -474,8 +535,13 @@ struct EKStep {
       double nrm2 = 0.0;
 #pragma unroll
       for (int i = k; i < d2; ++i) nrm2 += G[i][k] * G[i][k];
+      // a zero column (H L1 = 0: zero predicted covariance in the measured directions) has no reflector: R_kk = 0,
+      // its reciprocal is taken as 0 like the reciprocal of a zero Cholesky pivot, beta = 0 below
+      const bool nz = nrm2 > 0.0;
       double nrm, rnrm;
-      sqrt_and_rsqrt(nrm2, nrm, rnrm);
+      sqrt_and_rsqrt(nz ? nrm2 : 1.0, nrm, rnrm);
+      nrm = nz ? nrm : 0.0;
+      rnrm = nz ? rnrm : 0.0;
       const double x0 = G[k][k];
       const double alpha = (x0 >= 0.0) ? -nrm : nrm;
       Rdinv[k] = (x0 >= 0.0) ? -rnrm : rnrm;  // 1 / R[k][k]

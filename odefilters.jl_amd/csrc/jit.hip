@@ -137,9 +137,16 @@ bool compile(const std::string& src, const std::string& include_dir, std::vector
     return false;
   }
   const std::string base = dir, srcp = base + "/rhs.hip", outp = base + "/rhs.co", logp = base + "/log.txt";
-  if (FILE* f = fopen(srcp.c_str(), "wb")) {
-    fwrite(src.data(), 1, src.size(), f);
-    fclose(f);
+  {
+    FILE* f = fopen(srcp.c_str(), "wb");
+    const bool written = f && fwrite(src.data(), 1, src.size(), f) == src.size();
+    if (f && fclose(f) != 0) { /* reported below through `written` of the next open */ }
+    if (!written) {
+      err = "odef_rhs_compile: cannot write the generated source to " + srcp;
+      remove(srcp.c_str());
+      rmdir(dir);
+      return false;
+    }
   }
   const std::string inc = "-I" + (include_dir.empty() ? default_include_dir() : include_dir);
   const char* env_cc = getenv("ODEFILTER_HIP_HIPCC");
@@ -219,23 +226,30 @@ bool jit_lookup(int rhs_id, int* d, int* np) {
 }
 
 JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& err) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  const int k = rhs_id - kJitFirstId;
-  if (k < 0 || k >= (int)g_rhs.size()) {
-    err = "unknown run-time rhs id";
-    return nullptr;
-  }
+  // The hipcc child process takes seconds to minutes: it runs OUTSIDE the registry lock, so that odef_create for other
+  // vector fields (jit_lookup, cached modules) is not blocked meanwhile.  Two threads asking for the same uncached
+  // module may both compile; the first to publish wins, the other's module is unloaded.
   const auto key = std::make_tuple(rhs_id, q, ek1, device);
-  auto it = g_modules.find(key);
-  if (it != g_modules.end()) return it->second.get();
-  const JitRhs& r = g_rhs[k];
+  JitRhs r;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int k = rhs_id - kJitFirstId;
+    if (k < 0 || k >= (int)g_rhs.size()) {
+      err = "unknown run-time rhs id";
+      return nullptr;
+    }
+    auto it = g_modules.find(key);
+    if (it != g_modules.end()) return it->second.get();
+    r = g_rhs[k];  // copy: the vector may grow while we compile
+  }
   auto m = std::make_unique<JitModule>();
   m->posterior = r.d * (q + 1) <= 12;  // the lane smoother / dense output / sampler keep a packed matrix per lane in LDS
   m->rows_team = r.d * (q + 1) <= 16 ? 16 : 32;
   std::vector<char> code;
   if (!compile(translation_unit(r, q, ek1, m->posterior), r.include_dir, code, err)) return nullptr;
-  if (hipModuleLoadData(&m->mod, code.data()) != hipSuccess) {
-    err = "hipModuleLoadData failed for the run-time compiled vector field";
+  const hipError_t le = hipModuleLoadData(&m->mod, code.data());
+  if (le != hipSuccess) {
+    err = std::string("hipModuleLoadData failed for the run-time compiled vector field: ") + hipGetErrorString(le);
     return nullptr;
   }
   struct { hipFunction_t* f; const char* name; bool need; } fn[] = {
@@ -251,6 +265,12 @@ JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& e
       (void)hipModuleUnload(m->mod);
       return nullptr;
     }
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_modules.find(key);
+  if (it != g_modules.end()) {  // somebody else published it meanwhile
+    (void)hipModuleUnload(m->mod);
+    return it->second.get();
   }
   JitModule* out = m.get();
   g_modules[key] = std::move(m);

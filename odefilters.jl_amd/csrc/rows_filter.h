@@ -30,20 +30,6 @@
 
 namespace odef {
 
-// 1 / x for a positive normal x: v_rcp_f64 seed and two Newton steps (5 instructions; libm's division is 10+)
-__device__ inline double rcp_pos(double x) {
-#ifdef ODEF_HOST_EMUL
-  return 1.0 / x;
-#else
-  double y = __builtin_amdgcn_rcp(x);
-  double e = __builtin_fma(-x, y, 1.0);
-  y = __builtin_fma(y, e, y);
-  e = __builtin_fma(-x, y, 1.0);
-  y = __builtin_fma(y, e, y);
-  return y;
-#endif
-}
-
 // S = L D L' for a small symmetric matrix (lower triangle referenced): unit lower L (strict part written), the pivots
 // and their reciprocals.  A non-positive pivot zeroes its column (reciprocal 0), the semi-definite rule of ek_math.h
 // (the reference's Cholesky-failure branch, src/filtering.jl:38-47).
@@ -70,28 +56,6 @@ __device__ inline void ldl_small(const double (&S)[n][n], double (&L)[n][n], dou
       for (int k = 0; k < j; ++k) t -= L[i][k] * v[k];
       L[i][j] = t * inv;
     }
-  }
-}
-
-// P(h) = diag(h^(j-q-1/2)) and its inverse for a step size that differs from trajectory to trajectory (adaptive steps;
-// src/preconditioning.jl:1-17): running products from h^(-q-1/2) like the reference's, the reciprocals as a second
-// running product (inv(::Diagonal) to within an ulp) -- no division, no libm pow: the table is rebuilt by all 16 lanes
-// of a team at every attempted step.
-template <int q, int NB>
-__device__ inline void rows_precond_table(double h, double* tab) {
-  double hq = 1.0;
-#pragma unroll
-  for (int k = 0; k < q; ++k) hq *= h;
-  double sh, rsh;
-  sqrt_and_rsqrt(h, sh, rsh);
-  double val = rsh * rcp_pos(hq), ival = hq * sh;
-  const double rh = rcp_pos(h);
-#pragma unroll
-  for (int J = 0; J < NB; ++J) {
-    tab[kTabPJ + J] = val;
-    tab[kTabPIJ + J] = ival;
-    val *= h;
-    ival *= rh;
   }
 }
 
@@ -147,6 +111,9 @@ template <class RHS, int q, bool IS_EK1>
 struct RowsStep {
   static constexpr int d = RHS::d, NB = q + 1, D = d * NB, LD = tv::lds_ld(D);
   static constexpr int kLdsDoubles = tv::lds_rows(d, NB) * LD;  // the team's exchange rows
+  // adaptive kernel: + the lanes' rows of Q and the state before the attempt (restored when it is rejected), both kept
+  // out of the registers
+  static constexpr int kLdsDoublesAdaptive = kLdsDoubles + 2 * tv::kTeam * D;
   static_assert(D <= tv::kTeam, "row-per-lane filter: one lane per state component");
   static_assert(NB >= 2, "order >= 1");
   using TV = tv::TV;
@@ -156,7 +123,7 @@ struct RowsStep {
   __device__ static inline void run(const PriorConsts& pc, const RowsConsts<d, NB>& lc, const RowsScale<d, NB>& sc,
                                     const double* __restrict__ pl, int fixed_diffusion, bool want_loglik, int success_iter,
                                     double prev_global, const tv::Lds& lds, TV& m, TV (&xr)[D], double (&err_scale)[d],
-                                    StepAux& aux) {
+                                    StepAux& aux, int qm_lds_off = -1) {  // qm_lds_off >= 0: the lanes' rows of Q are in LDS there
     const double pi0 = sc.pijv[0], pi1 = sc.pijv[1];
     // x~ = P x (src/perform_step.jl:36-38)
     const TV mt = sc.pj * m;
@@ -258,8 +225,15 @@ struct RowsStep {
       for (int c = 0; c < D; ++c) zr[c] = tv::fma(lc.at[t], other[c], zr[c]);
     });
     tv::lds_sync();
+    if (qm_lds_off >= 0) {
+      TV qm[D];
+      tv::lds_get_private<D>(lds, qm_lds_off, qm);
 #pragma unroll
-    for (int c = 0; c < D; ++c) zr[c] = tv::fma(sigma2_pred, lc.qm[c], zr[c]);
+      for (int c = 0; c < D; ++c) zr[c] = tv::fma(sigma2_pred, qm[c], zr[c]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < D; ++c) zr[c] = tv::fma(sigma2_pred, lc.qm[c], zr[c]);
+    }
 
     // C = Sigma^- H' (own row), S = H C = H Sigma^- H' (src/perform_step.jl:54)
     TV Cr[d];
@@ -501,8 +475,11 @@ __device__ inline void rows_filter_adaptive(const FilterParams& P, const RowsTea
   rows_initial_state<RHS, q>(P, i, pl, u0, m, xr);
   RowsConsts<d, NB> lc;
   lc.init(P.pc);
+  constexpr int kQmOff = S::kLdsDoubles, kOldOff = S::kLdsDoubles + tv::kTeam * D;
+  tv::lds_put_private<D>(lds, kQmOff, lc.qm);
+  tv::lds_sync();
   RowsSink<D, true, true> sink;
-  sink.init(tm, P.N, S::kLdsDoubles, S::LD, P.mean, P.cov, P.diff, P.tsave);
+  sink.init(tm, P.N, S::kLdsDoublesAdaptive, S::LD, P.mean, P.cov, P.diff, P.tsave);
   sink.stage_cov(lds, S::LD, xr);
 
   double ucur[d];
@@ -538,17 +515,15 @@ __device__ inline void rows_filter_adaptive(const FilterParams& P, const RowsTea
       // P(h) (src/preconditioning.jl:1-17): h^(-q-1/2) and the running products; reciprocals for inv(P)
       {
         double tab[kTabStride];
-        rows_precond_table<q, NB>(h, tab);
+        precond_table_fast<q, NB>(h, tab);
         sc.set(LocalTab{tab});
       }
       const tv::TV m_old = m;
-      tv::TV x_old[D];
-#pragma unroll
-      for (int c = 0; c < D; ++c) x_old[c] = xr[c];
+      tv::lds_put_private<D>(lds, kOldOff, xr);  // the state before the attempt: needed again only when it is rejected
       double es[d];
       StepAux aux;
       aux.chol_fix = 0;
-      S::run(P.pc, lc, sc, pl, P.fixed_diffusion, P.want_loglik != 0, naccept, gdiff, lds, m, xr, es, aux);
+      S::run(P.pc, lc, sc, pl, P.fixed_diffusion, P.want_loglik != 0, naccept, gdiff, lds, m, xr, es, aux, kQmOff);
       // DiffEqBase.calculate_residuals! + ODE_DEFAULT_NORM (src/perform_step.jl:78-84)
       double unew[d];
       tv::bcast_lanes<0, d>(m, unew);
@@ -575,8 +550,7 @@ __device__ inline void rows_filter_adaptive(const FilterParams& P, const RowsTea
       if (!(EEst < 1.0)) {
         // x_filt is not committed (src/perform_step.jl:89): cache.x stays P^-1 (P x) of the old state (:73)
         m = sc.pij * (sc.pj * m_old);
-#pragma unroll
-        for (int c = 0; c < D; ++c) xr[c] = x_old[c];
+        tv::lds_get_private<D>(lds, kOldOff, xr);
         sink.stage_cov(lds, S::LD, xr);  // the exchange rows hold the rejected candidate
       }
       if (accepted) {

@@ -25,6 +25,8 @@ namespace odef {
 template <int d, int q, bool ADAPT>
 struct RowsSmoother {
   static constexpr int NB = q + 1, D = d * NB, TRI = D * (D + 1) / 2, LD = tv::lds_ld(D);
+  static constexpr int kExchange = tv::lds_rows(d, NB) * LD;            // the team's exchange rows (doubles)
+  static constexpr int kLdsDoubles = kExchange + tv::kTeam * D;         // + the lanes' rows of Q (kept out of the registers)
   static_assert(D <= tv::kTeam, "row-per-lane smoother: one lane per state component");
   using TV = tv::TV;
 
@@ -63,14 +65,16 @@ struct RowsSmoother {
   __device__ inline void run(const SmoothParams& P, const RowsTeam& tm, long n_hi) {
     const long i = tm.i;
     const tv::Lds lds{tm.lds_team};
-    tv::lds_clear(lds, tv::lds_rows(d, NB) * LD);
+    tv::lds_clear(lds, kExchange);
     init_offsets(P.N, i);
     RowsConsts<d, NB> lc;
     lc.init(P.pc);
+    tv::lds_put_private<D>(lds, kExchange, lc.qm);  // row r of Q = Qt (x) I_d: 2 D registers the step can use otherwise
+    tv::lds_sync();
     const PriorConsts& pc = P.pc;
     const long n = !tm.valid ? 0 : ADAPT ? (long)P.nsaved[i] : P.n_save;
     RowsSink<D, false, false> sink;
-    sink.init(tm, P.N, tv::lds_rows(d, NB) * LD, LD, P.smean, P.scov, nullptr, nullptr);
+    sink.init(tm, P.N, kLdsDoubles, LD, P.smean, P.scov, nullptr, nullptr);
 
     TV ms = tv::splat(0.0), csr[D];
 #pragma unroll
@@ -110,7 +114,7 @@ struct RowsSmoother {
       if (step) {
       if constexpr (ADAPT) {
         double tab[kTabStride];
-        rows_precond_table<q, NB>(h, tab);
+        precond_table_fast<q, NB>(h, tab);
         sc.set(LocalTab{tab});
       } else {
         const int ti = uniform_load(P.tab_idx + s);
@@ -160,32 +164,35 @@ struct RowsSmoother {
         for (int c = 0; c < D; ++c) lr[c] = tv::fma(lc.at[t], other[c], lr[c]);
       });
       tv::lds_sync();
+      {
+        TV qm[D];
+        tv::lds_get_private<D>(lds, kExchange, qm);
 #pragma unroll
-      for (int c = 0; c < D; ++c) lr[c] = tv::fma(sigma2, lc.qm[c], lr[c]);
+        for (int c = 0; c < D; ++c) lr[c] = tv::fma(sigma2, qm[c], lr[c]);
+      }
       // M = P Sigma^s_{i+1} P - Sigma^- ; delta = P m^s_{i+1} - m^-
       TV Mr[D];
 #pragma unroll
       for (int c = 0; c < D; ++c) Mr[c] = csr[c] * sc.f[c / d] - lr[c];
       const TV delta = sc.pj * ms - mp;
-      // B = L D L' (right-looking; lane r ends with row r of the unit-lower factor in lr[c < r]).  A non-positive
-      // pivot zeroes its column (the semi-definite rule of ek_math.h).
-      double dinv[D];
+      // B = L D L' (right-looking; lane r ends with row r of the unit-lower factor in lr[c < r]; a non-positive pivot
+      // zeroes its column, the semi-definite rule of ek_math.h) ...
+      // ... with the forward substitution of G = Y B^-1 riding along (own row y: u L' = y, w = u D^-1): at column k the
+      // entry w_k = u_k / D_k is final and the later entries lose B[j][k] w_k -- the same broadcasts as the factorisation
       static_for<0, D>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         const double piv = tv::bcast<k>(lr[k]);
         const bool ok = piv > 0.0;
-        dinv[k] = ok ? rcp_pos(ok ? piv : 1.0) : 0.0;
-        const TV lik = lr[k] * dinv[k];
-        tv::fb_cols<true, k + 1, D - k - 1>(lr, lr[k], lik);  // lr[j] -= l_rk * B[j][k], j > k
+        const double dinv = ok ? rcp_pos(ok ? piv : 1.0) : 0.0;
+        const TV colk = lr[k];  // lane j: B[j][k] of the current Schur complement
+        const TV lik = colk * dinv;
+        const TV wk = yr[k] * dinv;
+        tv::fb_cols<true, k + 1, D - k - 1>(lr, colk, lik);  // lr[j] -= l_rk B[j][k], j > k
+        tv::fb_cols<true, k + 1, D - k - 1>(yr, colk, wk);   // y[j]  -= w_k  B[j][k], j > k
         lr[k] = lik;
+        yr[k] = wk;
       });
-      // G = Y B^-1, own row:  u L' = y  (u_k = y_k - sum_{c<k} u_c L[k][c]),  w = u D^-1,  g L = w
-      static_for<1, D>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        tv::fb_dot<true, k, k>(yr[k], lr, yr);  // L[k][c] = bcast<k>(lr[c])
-      });
-#pragma unroll
-      for (int k = 0; k < D; ++k) yr[k] = yr[k] * dinv[k];
+      // ... and backwards: g L = w
       static_for<1, D>([&](auto jc) {
         constexpr int k = D - 1 - decltype(jc)::value;  // k = D-2 .. 0
         tv::fb_lanes<true, k + 1, D - k - 1>(yr[k], lr[k], yr);  // L[c][k] = bcast<c>(lr[k]), c > k

@@ -217,6 +217,17 @@ inline void lds_get_sym(const Lds& m, int LD, const SymIdx<n>&, TV (&out)[n]) {
     for (int c = 0; c < n; ++c) out[c].v[l] = (l >= c) ? m.p[l * LD + c] : m.p[c * LD + l];
 }
 inline void lds_sync() {}
+// lane-private table in the team's LDS (constants that would otherwise sit in registers): lane r owns p[off + r * n ..]
+template <int n>
+inline void lds_put_private(const Lds& m, int off, const TV (&v)[n]) {
+  for (int l = 0; l < kTeam; ++l)
+    for (int c = 0; c < n; ++c) m.p[off + l * n + c] = v[c].v[l];
+}
+template <int n>
+inline void lds_get_private(const Lds& m, int off, TV (&v)[n]) {
+  for (int l = 0; l < kTeam; ++l)
+    for (int c = 0; c < n; ++c) v[c].v[l] = m.p[off + l * n + c];
+}
 
 // ---- record fields in global memory, layout [slot][row][N]: per-lane byte offsets inside one slot -----------
 // offsets of element `row_of_lane(r)` for trajectory i; lanes with row < 0 take no part
@@ -360,38 +371,98 @@ ODEF_TV_INLINE void bcast_vec(const double* src, double* out) {
 // group no instruction reads through DPP a register the group writes (the accumulators are never DPP sources), so
 // nothing inside needs a wait state.
 #define ODEF_TV_DPPCTL " row_mask:0xf bank_mask:0xf\n\t"
+#define ODEF_TV_DPPEND " row_mask:0xf bank_mask:0xf"
+// cols: accumulators acc[C0..], one source, one multiplier, lanes C0..
 #define ODEF_TV_FB4_COLS(SGN)                                                                          \
   asm("s_nop 1\n\t"                                                                                    \
       "v_fmac_f64_dpp %0, " SGN "%4, %5 row_newbcast:%6" ODEF_TV_DPPCTL                                \
       "v_fmac_f64_dpp %1, " SGN "%4, %5 row_newbcast:%7" ODEF_TV_DPPCTL                                \
       "v_fmac_f64_dpp %2, " SGN "%4, %5 row_newbcast:%8" ODEF_TV_DPPCTL                                \
-      "v_fmac_f64_dpp %3, " SGN "%4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"                    \
+      "v_fmac_f64_dpp %3, " SGN "%4, %5 row_newbcast:%9" ODEF_TV_DPPEND                                \
       : "+v"(acc[C0]), "+v"(acc[C0 + 1]), "+v"(acc[C0 + 2]), "+v"(acc[C0 + 3])                         \
       : "v"(src), "v"(b), "n"(C0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3))
+#define ODEF_TV_FB3_COLS(SGN)                                                                          \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_fmac_f64_dpp %0, " SGN "%3, %4 row_newbcast:%5" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %1, " SGN "%3, %4 row_newbcast:%6" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %2, " SGN "%3, %4 row_newbcast:%7" ODEF_TV_DPPEND                                \
+      : "+v"(acc[C0]), "+v"(acc[C0 + 1]), "+v"(acc[C0 + 2])                                            \
+      : "v"(src), "v"(b), "n"(C0), "n"(C0 + 1), "n"(C0 + 2))
+#define ODEF_TV_FB2_COLS(SGN)                                                                          \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_fmac_f64_dpp %0, " SGN "%2, %3 row_newbcast:%4" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %1, " SGN "%2, %3 row_newbcast:%5" ODEF_TV_DPPEND                                \
+      : "+v"(acc[C0]), "+v"(acc[C0 + 1])                                                               \
+      : "v"(src), "v"(b), "n"(C0), "n"(C0 + 1))
+// rows: accumulators acc[0..], sources src[0..], one multiplier, one lane K
 #define ODEF_TV_FB4_ROWS(SGN)                                                                          \
   asm("s_nop 1\n\t"                                                                                    \
       "v_fmac_f64_dpp %0, " SGN "%4, %8 row_newbcast:%9" ODEF_TV_DPPCTL                                \
       "v_fmac_f64_dpp %1, " SGN "%5, %8 row_newbcast:%9" ODEF_TV_DPPCTL                                \
       "v_fmac_f64_dpp %2, " SGN "%6, %8 row_newbcast:%9" ODEF_TV_DPPCTL                                \
-      "v_fmac_f64_dpp %3, " SGN "%7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"                    \
+      "v_fmac_f64_dpp %3, " SGN "%7, %8 row_newbcast:%9" ODEF_TV_DPPEND                                \
       : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                         \
       : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(b), "n"(K))
+#define ODEF_TV_FB3_ROWS(SGN)                                                                          \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_fmac_f64_dpp %0, " SGN "%3, %6 row_newbcast:%7" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %1, " SGN "%4, %6 row_newbcast:%7" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %2, " SGN "%5, %6 row_newbcast:%7" ODEF_TV_DPPEND                                \
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2])                                                       \
+      : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(b), "n"(K))
+#define ODEF_TV_FB2_ROWS(SGN)                                                                          \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_fmac_f64_dpp %0, " SGN "%2, %4 row_newbcast:%5" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %1, " SGN "%3, %4 row_newbcast:%5" ODEF_TV_DPPEND                                \
+      : "+v"(acc[0]), "+v"(acc[1])                                                                     \
+      : "v"(src[0]), "v"(src[1]), "v"(b), "n"(K))
+// dot: one accumulator, sources src[0..], multipliers b[0..], one lane K
 #define ODEF_TV_FB4_DOT(SGN)                                                                           \
   asm("s_nop 1\n\t"                                                                                    \
       "v_fmac_f64_dpp %0, " SGN "%1, %5 row_newbcast:%9" ODEF_TV_DPPCTL                                \
       "v_fmac_f64_dpp %0, " SGN "%2, %6 row_newbcast:%9" ODEF_TV_DPPCTL                                \
       "v_fmac_f64_dpp %0, " SGN "%3, %7 row_newbcast:%9" ODEF_TV_DPPCTL                                \
-      "v_fmac_f64_dpp %0, " SGN "%4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"                    \
+      "v_fmac_f64_dpp %0, " SGN "%4, %8 row_newbcast:%9" ODEF_TV_DPPEND                                \
       : "+v"(acc)                                                                                      \
       : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "n"(K))
+#define ODEF_TV_FB3_DOT(SGN)                                                                           \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_fmac_f64_dpp %0, " SGN "%1, %4 row_newbcast:%7" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %0, " SGN "%2, %5 row_newbcast:%7" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %0, " SGN "%3, %6 row_newbcast:%7" ODEF_TV_DPPEND                                \
+      : "+v"(acc)                                                                                      \
+      : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "n"(K))
+#define ODEF_TV_FB2_DOT(SGN)                                                                           \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_fmac_f64_dpp %0, " SGN "%1, %3 row_newbcast:%5" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %0, " SGN "%2, %4 row_newbcast:%5" ODEF_TV_DPPEND                                \
+      : "+v"(acc)                                                                                      \
+      : "v"(src[0]), "v"(src[1]), "v"(b[0]), "v"(b[1]), "n"(K))
+// lanes: one accumulator, one source, multipliers b[C0..], lanes C0..
 #define ODEF_TV_FB4_LANES(SGN)                                                                         \
   asm("s_nop 1\n\t"                                                                                    \
       "v_fmac_f64_dpp %0, " SGN "%1, %2 row_newbcast:%6" ODEF_TV_DPPCTL                                \
       "v_fmac_f64_dpp %0, " SGN "%1, %3 row_newbcast:%7" ODEF_TV_DPPCTL                                \
       "v_fmac_f64_dpp %0, " SGN "%1, %4 row_newbcast:%8" ODEF_TV_DPPCTL                                \
-      "v_fmac_f64_dpp %0, " SGN "%1, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"                    \
+      "v_fmac_f64_dpp %0, " SGN "%1, %5 row_newbcast:%9" ODEF_TV_DPPEND                                \
       : "+v"(acc)                                                                                      \
       : "v"(src), "v"(b[C0]), "v"(b[C0 + 1]), "v"(b[C0 + 2]), "v"(b[C0 + 3]), "n"(C0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3))
+#define ODEF_TV_FB3_LANES(SGN)                                                                         \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_fmac_f64_dpp %0, " SGN "%1, %2 row_newbcast:%5" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %0, " SGN "%1, %3 row_newbcast:%6" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %0, " SGN "%1, %4 row_newbcast:%7" ODEF_TV_DPPEND                                \
+      : "+v"(acc)                                                                                      \
+      : "v"(src), "v"(b[C0]), "v"(b[C0 + 1]), "v"(b[C0 + 2]), "n"(C0), "n"(C0 + 1), "n"(C0 + 2))
+#define ODEF_TV_FB2_LANES(SGN)                                                                         \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_fmac_f64_dpp %0, " SGN "%1, %2 row_newbcast:%4" ODEF_TV_DPPCTL                                \
+      "v_fmac_f64_dpp %0, " SGN "%1, %3 row_newbcast:%5" ODEF_TV_DPPEND                                \
+      : "+v"(acc)                                                                                      \
+      : "v"(src), "v"(b[C0]), "v"(b[C0 + 1]), "n"(C0), "n"(C0 + 1))
+#define ODEF_TV_FB_DISPATCH(M)   \
+  if constexpr (NEG) M("-");     \
+  else M("")
 template <bool NEG, int K>
 ODEF_TV_INLINE void fb1(double& acc, double src, double b) {
   if constexpr (NEG) fnma_bc<K>(acc, src, b);
@@ -400,45 +471,53 @@ ODEF_TV_INLINE void fb1(double& acc, double src, double b) {
 template <bool NEG, int C0, int n>
 ODEF_TV_INLINE void fb_cols(double* acc, double src, double b) {
   if constexpr (n >= 4) {
-    if constexpr (NEG) ODEF_TV_FB4_COLS("-");
-    else ODEF_TV_FB4_COLS("");
+    ODEF_TV_FB_DISPATCH(ODEF_TV_FB4_COLS);
     fb_cols<NEG, C0 + 4, n - 4>(acc, src, b);
-  } else if constexpr (n > 0) {
+  } else if constexpr (n == 3) {
+    ODEF_TV_FB_DISPATCH(ODEF_TV_FB3_COLS);
+  } else if constexpr (n == 2) {
+    ODEF_TV_FB_DISPATCH(ODEF_TV_FB2_COLS);
+  } else if constexpr (n == 1) {
     fb1<NEG, C0>(acc[C0], src, b);
-    fb_cols<NEG, C0 + 1, n - 1>(acc, src, b);
   }
 }
 template <bool NEG, int K, int n>
 ODEF_TV_INLINE void fb_rows(double* acc, const double* src, double b) {
   if constexpr (n >= 4) {
-    if constexpr (NEG) ODEF_TV_FB4_ROWS("-");
-    else ODEF_TV_FB4_ROWS("");
+    ODEF_TV_FB_DISPATCH(ODEF_TV_FB4_ROWS);
     fb_rows<NEG, K, n - 4>(acc + 4, src + 4, b);
-  } else if constexpr (n > 0) {
+  } else if constexpr (n == 3) {
+    ODEF_TV_FB_DISPATCH(ODEF_TV_FB3_ROWS);
+  } else if constexpr (n == 2) {
+    ODEF_TV_FB_DISPATCH(ODEF_TV_FB2_ROWS);
+  } else if constexpr (n == 1) {
     fb1<NEG, K>(acc[0], src[0], b);
-    fb_rows<NEG, K, n - 1>(acc + 1, src + 1, b);
   }
 }
 template <bool NEG, int K, int n>
 ODEF_TV_INLINE void fb_dot(double& acc, const double* src, const double* b) {
   if constexpr (n >= 4) {
-    if constexpr (NEG) ODEF_TV_FB4_DOT("-");
-    else ODEF_TV_FB4_DOT("");
+    ODEF_TV_FB_DISPATCH(ODEF_TV_FB4_DOT);
     fb_dot<NEG, K, n - 4>(acc, src + 4, b + 4);
-  } else if constexpr (n > 0) {
+  } else if constexpr (n == 3) {
+    ODEF_TV_FB_DISPATCH(ODEF_TV_FB3_DOT);
+  } else if constexpr (n == 2) {
+    ODEF_TV_FB_DISPATCH(ODEF_TV_FB2_DOT);
+  } else if constexpr (n == 1) {
     fb1<NEG, K>(acc, src[0], b[0]);
-    fb_dot<NEG, K, n - 1>(acc, src + 1, b + 1);
   }
 }
 template <bool NEG, int C0, int n>
 ODEF_TV_INLINE void fb_lanes(double& acc, double src, const double* b) {
   if constexpr (n >= 4) {
-    if constexpr (NEG) ODEF_TV_FB4_LANES("-");
-    else ODEF_TV_FB4_LANES("");
+    ODEF_TV_FB_DISPATCH(ODEF_TV_FB4_LANES);
     fb_lanes<NEG, C0 + 4, n - 4>(acc, src, b);
-  } else if constexpr (n > 0) {
+  } else if constexpr (n == 3) {
+    ODEF_TV_FB_DISPATCH(ODEF_TV_FB3_LANES);
+  } else if constexpr (n == 2) {
+    ODEF_TV_FB_DISPATCH(ODEF_TV_FB2_LANES);
+  } else if constexpr (n == 1) {
     fb1<NEG, C0>(acc, src, b[C0]);
-    fb_lanes<NEG, C0 + 1, n - 1>(acc, src, b);
   }
 }
 template <int C0, int n>
@@ -492,6 +571,18 @@ ODEF_TV_INLINE void lds_get_row(const Lds& m, int LD, double (&out)[n]) {
     out[c + 1] = t.y;
   }
   if constexpr (n % 2 == 1) out[n - 1] = q[n - 1];
+}
+template <int n>
+ODEF_TV_INLINE void lds_put_private(const Lds& m, int off, const double (&v)[n]) {
+  double* q = m.p + off + lane() * n;
+#pragma unroll
+  for (int c = 0; c < n; ++c) q[c] = v[c];
+}
+template <int n>
+ODEF_TV_INLINE void lds_get_private(const Lds& m, int off, double (&v)[n]) {
+  const double* q = m.p + off + lane() * n;
+#pragma unroll
+  for (int c = 0; c < n; ++c) v[c] = q[c];
 }
 template <int n>
 struct SymIdx {  // the lane's offsets of m[max(r,c)][min(r,c)], c = 0..n-1: computed once per kernel

@@ -526,6 +526,7 @@ class EnsembleHIP:
     `EnsembleSolution.gather_final()` is the single RCCL all-gather of the path."""
     device: int = -1
     distributed: bool = False
+    backend: str = "nccl"  # torch.distributed backend of the distributed path ("nccl" = RCCL over xGMI; "gloo" for CPU tests)
 
 
 def shard_ensemble(prob: "EnsembleProblem", trajectories: Optional[int], rank: int, world: int):
@@ -547,18 +548,25 @@ def shard_ensemble(prob: "EnsembleProblem", trajectories: Optional[int], rank: i
     return local, hi - lo, (lo, hi)
 
 
-def fixed_time_grid(t0: float, t1: float, dt: float) -> np.ndarray:
-    """OrdinaryDiffEq's fixed-step grid: t += dt, last step clipped onto the tstop."""
+def fixed_time_grid(t0: float, t1: float, dt: float, tstops: Optional[Sequence[float]] = None) -> np.ndarray:
+    """OrdinaryDiffEq's fixed-step grid: t += dt, every step clipped onto the next tstop (the end of the time span is
+    one), with the 100-eps snap of the integrator loop."""
+    if not (np.isfinite(dt) and dt > 0.0):
+        raise OdefError(f"dt must be positive and finite, got {dt!r}")
+    if not (t1 > t0):
+        raise OdefError(f"tspan must be increasing, got ({t0!r}, {t1!r})")
+    stops = sorted({float(x) for x in (tstops if tstops is not None else []) if t0 < float(x) < t1} | {float(t1)})
     ts = [t0]
     t = t0
     eps = np.finfo(float).eps
-    while t < t1:
-        h = min(dt, t1 - t)
-        tn = t + h
-        if abs(tn - t1) < 100 * eps * max(abs(tn), abs(t1)):
-            tn = t1
-        ts.append(tn)
-        t = tn
+    for stop in stops:
+        while t < stop:
+            h = min(dt, stop - t)
+            tn = t + h
+            if abs(tn - stop) < 100 * eps * max(abs(tn), abs(stop)):
+                tn = stop
+            ts.append(tn)
+            t = tn
     return np.array(ts)
 
 
@@ -611,7 +619,8 @@ class EnsembleSolution:
 
         lo, hi, total, world = self.shard
         rows = -(-total // world)
-        dev = torch.device("cuda", torch.cuda.current_device()) if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
+        # the GPU this rank's context runs on (RCCL needs one distinct device per rank: never "the current device")
+        dev = torch.device("cuda", int(self.ctx.cfg.device)) if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
         buf = torch.zeros((rows, self.D), dtype=torch.float64, device=dev)
         buf[: hi - lo] = torch.from_numpy(mine).to(dev)
         g = od.allgather_shards(buf, world).cpu().numpy()  # [world, rows, D]
@@ -757,8 +766,15 @@ def solve(prob, alg, ensemblealg: EnsembleHIP = EnsembleHIP(), *, trajectories: 
           max_steps: Optional[int] = None, want_loglik: bool = True) -> EnsembleSolution:
     """`solve(EnsembleProblem(prob), EK1(order=3), EnsembleHIP(); trajectories, dt, adaptive, abstol, reltol)`.
 
-    Keyword meaning follows DifferentialEquations.jl: `adaptive=false` needs `dt` (or `tstops`
-    as the full grid); with `adaptive=true`, `dt` is the initial step."""
+    Keyword meaning follows DifferentialEquations.jl: `adaptive=false` needs `dt` (steps clipped onto `tstops` and the
+    end of the time span) or `tstops` alone as the full grid; with `adaptive=true`, `dt` is the initial step.
+
+    Differences from the reference's defaults, stated: (i) without `dt` an adaptive solve starts with 1e-3 (t1 - t0),
+    not with OrdinaryDiffEq's automatic initial step (that heuristic evaluates `f` on the host; the vector field
+    lives on the device) -- `sol.t` / `destats` then differ from the reference's, the posterior at common times does
+    not beyond the tolerances; (ii) the device keeps one record per ATTEMPTED step, so the step budget is
+    `max_steps` (default: `maxiters`, capped so that the records stay below 8 GiB); a trajectory that exhausts it ends
+    with retcode MaxIters and a RuntimeWarning is raised, as for any other non-Success retcode."""
     if isinstance(prob, ODEProblem):
         prob = EnsembleProblem(prob, u0s=np.asarray(prob.u0, float)[None, :])
         trajectories = 1
@@ -766,14 +782,18 @@ def solve(prob, alg, ensemblealg: EnsembleHIP = EnsembleHIP(), *, trajectories: 
     if ensemblealg.distributed:
         from . import dist as od
 
-        rank, world, local_rank = od.init_from_env(backend="nccl")
+        rank, world, local_rank = od.init_from_env(backend=ensemblealg.backend)
+        if ensemblealg.backend == "nccl":
+            import torch
+
+            torch.cuda.set_device(local_rank if ensemblealg.device < 0 else ensemblealg.device)
         total = len(prob.u0s) if prob.u0s is not None else trajectories
         prob, trajectories, (lo, hi) = shard_ensemble(prob, trajectories, rank, world)
         if hi == lo:
             raise OdefError(f"rank {rank} of {world} received no trajectory (ensemble of {total})")
         shard = (lo, hi, int(total), world)
         if ensemblealg.device < 0:
-            ensemblealg = EnsembleHIP(device=local_rank, distributed=True)
+            ensemblealg = EnsembleHIP(device=local_rank, distributed=True, backend=ensemblealg.backend)
     base = prob.prob
     if alg.prior != "ibm":
         raise OdefError("Only the ibm prior is implemented so far")  # src/caches.jl:69
@@ -803,14 +823,29 @@ def solve(prob, alg, ensemblealg: EnsembleHIP = EnsembleHIP(), *, trajectories: 
         if prob.perturb_scale is None:
             raise OdefError("EnsembleProblem needs u0s or perturb_scale")
         ctx.set_problem_perturbed(base.u0, p, t0, prob.perturb_scale, prob.seed, prob.first_index, prob.n_perturbed)
+    if not (t1 > t0):
+        raise OdefError(f"tspan must be increasing, got ({t0!r}, {t1!r})")
     if adaptive:
-        ms = max_steps if max_steps is not None else 4096
+        if dt is not None and not (np.isfinite(dt) and dt > 0.0):
+            raise OdefError(f"dt must be positive and finite, got {dt!r}")
+        if max_steps is not None:
+            ms = int(max_steps)
+        else:  # maxiters attempts, bounded by the memory of one record per attempt
+            rec_bytes = 8 * (ctx.D + ctx.TRI + 2) * (2 if alg.smooth else 1)
+            ms = int(max(64, min(int(maxiters), (8 << 30) // (rec_bytes * N))))
         ctx.solve_adaptive(t1, abstol, reltol, dt if dt is not None else 1e-3 * (t1 - t0), None, ms)
     else:
-        grid = np.asarray(tstops, float) if (tstops is not None and dt is None) else fixed_time_grid(t0, t1, dt)
+        grid = np.asarray(tstops, float) if (tstops is not None and dt is None) else fixed_time_grid(t0, t1, dt, tstops)
         ctx.solve_fixed(grid)
     sol = EnsembleSolution(ctx, alg, adaptive)
     sol.shard = shard
     if alg.smooth and ctx.cfg.save_mode == SAVE_EVERYSTEP:
         ctx.smooth()
+    bad = np.flatnonzero(sol.retcode_raw != 0)
+    if bad.size:
+        import warnings
+
+        kinds = sorted({RETCODES[int(r)] for r in sol.retcode_raw[bad]})
+        warnings.warn(f"{bad.size} of {N} trajectories did not finish with Success ({', '.join(kinds)}; first: trajectory "
+                      f"{int(bad[0])}); see sol.retcode", RuntimeWarning, stacklevel=2)
     return sol

@@ -3,17 +3,27 @@
 Tolerances.  The hard bar of BASELINE.json (posterior means of the solution within 1e-8
 relative) is asserted at 1e-10 on E0*mu (`sol.u`).  Higher-derivative components of the
 state and the covariances are *ill-conditioned in the reference's own arithmetic*: a 1-ulp
-change of u0 moves the reference's u''' by up to 1e-8 relative on Lorenz-63 (mpmath
-experiment recorded in DESIGN.md: both the oracle and the HIP arithmetic sit at the same
-distance from a 40-digit evaluation).  For those quantities the tolerance is calibrated on
-the oracle itself: `noise` = spread of the oracle under 1-ulp input perturbations, and two
-fp64 implementations are required to agree within NOISE_FACTOR (1000) x noise (+ a 1e-12 floor).
+change of u0 moves the reference's u''' by up to 1e-8 relative on Lorenz-63.
+
+Where an EXACT evaluation of the reference algorithm exists (tests/golden/exact_lorenz_mp.npz: mpmath, 50 digits,
+1 024 steps, filter and smoother; exact_pleiades_ld.npz: x87 extended precision, 24 steps; generator
+tests/golden/make_exact.py) the question asked is the right one -- is the device as close to the exact result as the
+float64 oracle is: `check_against_exact` requires |device - exact| <= EXACT_FACTOR x |oracle - exact| per derivative
+block and for the covariance.  Measured ratios (tests/test_emul_parity.py prints nothing, the numbers are in DESIGN.md
+section 4): lane kernels 1.3-2.0, row-team kernels 0.4-9.7, tiled D = 168 kernel 0.9-12.
+
+Elsewhere the tolerance is calibrated on the oracle itself: `noise` = spread of the oracle under 1-ulp input
+perturbations, and two fp64 implementations are required to agree within NOISE_FACTOR x noise (+ a 1e-11 floor).
+The factor is tied to the exact fixtures: on Lorenz-63 the oracle's 1-ulp spread is 2x its distance from the exact
+result, a device 12x as far from exact as the oracle is therefore at most (12 + 1) / 2 = 6.5 noise units from the oracle;
+NOISE_FACTOR = 64 leaves a decade of margin for problems without an exact fixture (round 1 used 1000 with no fixture).
 """
 import numpy as np
 
 import odefilter_oracle as orc
 
-NOISE_FACTOR = 1000.0
+NOISE_FACTOR = 64.0
+EXACT_FACTOR = 16.0
 U_RTOL = 1e-10
 FLOOR = 1e-11
 
@@ -71,4 +81,16 @@ def check_against_oracle(mean, cov, ref_mean, ref_cov, d, noise_m, noise_c, what
     ce = cov_err(cov, ref_cov)
     ctol = max(1e-9, NOISE_FACTOR * noise_c)
     assert ce <= ctol, f"{what}: covariance error {ce:.2e} exceeds calibrated tolerance {ctol:.2e}"
+    return be, ce
+
+
+def check_against_exact(mean, cov, exact_mean, exact_cov, oracle_block_err, oracle_cov_err, d, what=""):
+    """|device - exact| <= EXACT_FACTOR x |oracle - exact|, per derivative block (floor: 4 ulp of the block scale) and for
+    the covariance; the solution block additionally at U_RTOL."""
+    be = block_err(mean, exact_mean, d)
+    assert be[0] <= U_RTOL, f"{what}: posterior mean of the solution off by {be[0]:.2e} from the exact result"
+    tol = np.maximum(EXACT_FACTOR * np.asarray(oracle_block_err), 1e-15)
+    assert np.all(be <= tol), f"{what}: block errors vs exact {be} exceed {EXACT_FACTOR} x the oracle's {oracle_block_err}"
+    ce = cov_err(cov, exact_cov)
+    assert ce <= EXACT_FACTOR * float(oracle_cov_err), f"{what}: covariance error vs exact {ce:.2e} exceeds {EXACT_FACTOR} x the oracle's {float(oracle_cov_err):.2e}"
     return be, ce

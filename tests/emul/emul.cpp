@@ -64,7 +64,7 @@ struct RunFilter {
       const long i0 = (i / 64) * 64;
       if (P.stagger == 9) {  // row-per-lane team filter (rows_filter.h): one 16-lane team per trajectory
         if constexpr (RHS::d * (q + 1) <= 16) {
-          std::vector<double> ws(tv::lds_rows(RHS::d, q + 1) * tv::lds_ld(RHS::d * (q + 1)));
+          std::vector<double> ws(RowsStep<RHS, q, EK1>::kLdsDoublesAdaptive);
           const RowsTeam tm{i, i, true, 0, ws.data(), nullptr};
           if (adaptive) rows_filter_adaptive<RHS, q, EK1>(P, tm);
           else if (P.everystep) rows_filter_fixed<RHS, q, EK1, true>(P, tm);
@@ -86,7 +86,7 @@ struct RunSmooth {
   void operator()() {
     if constexpr (d * (q + 1) <= 16) {
       if (bcast_rows) {
-        std::vector<double> ws(tv::lds_rows(d, q + 1) * tv::lds_ld(d * (q + 1)));
+        std::vector<double> ws(RowsSmoother<d, q, false>::kLdsDoubles);
         for (long i = 0; i < P.N; ++i) {
           const RowsTeam tm{i, i, true, 0, ws.data(), nullptr};
           if (P.adaptive) {

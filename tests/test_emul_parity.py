@@ -1,6 +1,8 @@
 """The per-lane device source (odefilters.jl_amd/csrc/ek_lane.h), compiled for the host by
 tests/emul, against the oracle.  Catches arithmetic bugs in the kernel source without a GPU.
 The GPU tests (test_gpu_parity.py) repeat these through the C ABI on the real kernels."""
+import os
+
 import numpy as np
 import pytest
 
@@ -372,3 +374,55 @@ def test_row_team_adaptive_rejections_and_limits():
     nf = rf["nsaved"][0]
     assert nf == len(fx.t)
     np.testing.assert_allclose(rf["mean"][0][:nf, :3], fx.means(smoothed=False)[:, :3], rtol=1e-7)
+
+
+@pytest.mark.parametrize("kernel", ["lane", "lagged", "rows"])
+def test_zero_pivots_and_zero_reflector_norms(kernel):
+    """The Cholesky-failure branch of the reference (src/filtering.jl:38-47) at its extreme: u' = 0 (linear field with
+    p = 0) has z = 0 exactly, hence sigma^2 = 0 and a ZERO predicted covariance -- every Cholesky pivot and every
+    reflector norm of the step is 0.  The reference's QR fallback yields a zero factor and then stops in inv(S) of a
+    singular S; the kernels' zero-pivot rule (column zeroed, reciprocal taken as 0) must return the exact constant
+    solution with zero covariance and no NaN (round 1 left rsq(0) * 0 = NaN in the reflector norm)."""
+    vf = orc.vector_field("linear")
+    u0 = np.array([[0.75, -1.25], [2.0, 3.0]])
+    tg = np.arange(17) * 2.0**-6
+    ev = {"lane": True, "lagged": 2, "rows": 3}[kernel]
+    for q in (1, 3):
+        r = E.emul_solve(vf.rhs_id, 2, q, True, u0, np.zeros(2), tgrid=tg, everystep=ev, smooth=True)
+        assert (r["retcode"] == 0).all()
+        np.testing.assert_array_equal(r["mean"][:, :, :2], np.broadcast_to(u0[:, None, :], (2, 17, 2)))
+        assert np.all(r["mean"][:, :, 2:] == 0.0) and np.all(r["cov"] == 0.0) and np.all(r["diff"] == 0.0)
+        np.testing.assert_array_equal(r["smean"][:, :, :2], r["mean"][:, :, :2])
+        assert np.all(r["scov"] == 0.0)
+
+
+# ---- against EXACT evaluations of the reference algorithm (tests/golden/make_exact.py) --------------------------------
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("kernel", ["lane", "rows"])
+def test_lorenz_1024_steps_against_50_digit_evaluation(kernel):
+    """BASELINE configs 2/3 (trajectory 0, all 1 024 steps), filter and smoother: the kernels' arithmetic (run on the host)
+    is as close to the 50-digit mpmath evaluation of the reference algorithm as the float64 oracle is, block by block."""
+    fx = np.load(os.path.join(GOLD, "exact_lorenz_mp.npz"))
+    vf = orc.vector_field("lorenz63")
+    tg = np.arange(int(fx["nsteps"]) + 1) * float(fx["dt"])
+    r = E.emul_solve(vf.rhs_id, 3, 3, True, fx["u0"][None, :], vf.p, tgrid=tg, everystep={"lane": True, "rows": 3}[kernel], smooth=True)
+    P.check_against_exact(r["mean"][0], r["cov"][0], fx["mean_filt"], fx["cov_filt"], fx["oracle_block_err_filt"],
+                          fx["oracle_cov_err_filt"], 3, f"{kernel} filter")
+    P.check_against_exact(r["smean"][0], r["scov"][0], fx["mean_smooth"], fx["cov_smooth"], fx["oracle_block_err_smooth"],
+                          fx["oracle_cov_err_smooth"], 3, f"{kernel} smoother")
+    np.testing.assert_allclose(r["diff"][0][1:], fx["diffusions"], rtol=2e-3)  # a squared residual: noise of u''' twice over
+
+
+def test_pleiades_24_steps_against_extended_precision():
+    """BASELINE config 4 at test size: the tiled D = 168 filter against an x87-extended evaluation."""
+    fx = np.load(os.path.join(GOLD, "exact_pleiades_ld.npz"))
+    vf = orc.vector_field("pleiades")
+    tg = np.arange(int(fx["nsteps"]) + 1) * float(fx["dt"])
+    r = E.emul_solve(vf.rhs_id, 28, 5, True, fx["u0"][None, :], vf.p, team="tiles", tgrid=tg)
+    be = P.block_err(r["mean"][0], fx["mean_filt"], 28)
+    assert be[0] <= P.U_RTOL
+    assert np.all(be <= np.maximum(P.EXACT_FACTOR * fx["oracle_block_err_filt"], 1e-15)), (be, fx["oracle_block_err_filt"])
+    assert P.cov_err(r["cov"][0][-1:], fx["cov_final"][None]) <= P.EXACT_FACTOR * float(fx["oracle_cov_err_final"])

@@ -78,3 +78,22 @@ def test_user_vector_field_compiles_without_a_gpu(pkg):
         pkg.compile_rhs("WrongDim", USER_LORENZ.replace("UserLorenz", "WrongDim"), 2, 3)
     with pytest.raises(pkg.OdefError, match="d must be in 1..10"):
         pkg.compile_rhs("TooBig", USER_LORENZ.replace("UserLorenz", "TooBig"), 12, 3)
+
+
+def test_fixed_time_grid_validation_and_tstops(pkg):
+    """`dt <= 0` or a decreasing time span must raise instead of looping forever; `tstops` are hit exactly
+    and combine with `dt` as in OrdinaryDiffEq's loop."""
+    from odefilters_jl_amd import host
+
+    for bad in (0.0, -1e-3, float("nan"), float("inf")):
+        with pytest.raises(host.OdefError):
+            host.fixed_time_grid(0.0, 1.0, bad)
+    with pytest.raises(host.OdefError):
+        host.fixed_time_grid(1.0, 1.0, 0.1)
+    g = host.fixed_time_grid(0.0, 1.0, 0.25)
+    np.testing.assert_array_equal(g, [0.0, 0.25, 0.5, 0.75, 1.0])
+    g = host.fixed_time_grid(0.0, 1.0, 0.25, tstops=[0.3, 0.5, 2.0])
+    np.testing.assert_allclose(g, [0.0, 0.25, 0.3, 0.5, 0.75, 1.0], rtol=0, atol=1e-15)
+    assert 0.3 in g and 0.5 in g and g[-1] == 1.0
+    g = host.fixed_time_grid(0.0, 2.0, 2.0**-9)
+    assert len(g) == 1025 and np.all(np.diff(g) == 2.0**-9)  # BASELINE grid: exact binary steps, no clipping
