@@ -19,19 +19,23 @@ struct OdefConfig                      # odef_config, 56 bytes
     device::Int32; want_loglik::Int32; n_traj::Int64
 end
 
-const RHS_IDS = Dict(:fhn => 0, :lorenz63 => 1, :lotka_volterra => 2, :vanderpol => 3, :linear => 4)
+const RHS_IDS = Dict(:fhn => 0, :lorenz63 => 1, :lotka_volterra => 2, :vanderpol => 3, :linear => 4, :pleiades => 5)
 const DIFFUSIONS = Dict(:dynamic => 0, :fixed => 1, :fixedMAP => 2)   # src/caches.jl:89-96 (the MV models are not on the device)
 const F_MEAN, F_COV_TRIL, F_DIFFUSION, F_T, F_LOGLIK, F_NACCEPT, F_NREJECT, F_NF, F_NJAC, F_NSAVED,
       F_RETCODE, F_SMOOTH_MEAN, F_SMOOTH_COV_TRIL = 0:12
 const F_SAMPLES = 16
 const RETCODES = (:Success, :MaxIters, :DtLessThanMin, :Unstable, :Unstable)
 
-"""Ensemble algorithm: all trajectories of an `EnsembleProblem` on one GPU, one lane per trajectory."""
+"""Ensemble algorithm: all trajectories of an `EnsembleProblem` on one GPU (`devices` empty / one entry) or sharded
+over several GPUs of the node by THIS process (`devices = 0:7`): contiguous blocks of the trajectory index, nothing
+exchanged while stepping, one RCCL all-gather of the final posterior means at the end (`odef_group_*`, `odef_allgather`
+of include/odefilter.h; SURVEY.md 8e)."""
 struct EnsembleHIP <: DiffEqBase.EnsembleAlgorithm
     device::Int
     rhs::Symbol          # which compiled-in vector field `prob.f` corresponds to
+    devices::Vector{Int32}
 end
-EnsembleHIP(rhs::Symbol; device=-1) = EnsembleHIP(device, rhs)
+EnsembleHIP(rhs::Symbol; device=-1, devices=Int32[]) = EnsembleHIP(device, rhs, collect(Int32, devices))
 
 lasterr(ctx) = unsafe_string(ccall((:odef_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx))
 check(rc, ctx) = rc == 0 || error("libodefilter_hip: " * lasterr(ctx))
@@ -131,6 +135,61 @@ function DiffEqBase.__solve(eprob::DiffEqBase.EnsembleProblem, alg::Union{EK0,EK
                 retcode = [RETCODES[r + 1] for r in fetch(ctx, F_RETCODE, Int32, N)])
     finally
         ccall((:odef_destroy, LIB), Cvoid, (Ptr{Cvoid},), ctx)
+    end
+end
+
+
+grouperr(g) = unsafe_string(ccall((:odef_group_last_error, LIB), Cstring, (Ptr{Cvoid},), g))
+gcheck(rc, g) = rc == 0 || error("libodefilter_hip: " * grouperr(g))
+
+"""
+    solve_sharded(eprob, alg, ealg; trajectories, u0s, dt, adaptive, ...) -> (final_mean, shards, ctxs...)
+
+The multi-GPU path of `EnsembleHIP(rhs; devices = 0:7)`: one `odef_group` over `ealg.devices`, the whole ensemble handed
+over once (`odef_group_set_problem` cuts it into the shards of `odef_shard_range`), the shards' kernels running
+concurrently, and ONE collective at the end: `odef_allgather` leaves the final posterior means of all N trajectories,
+`final_mean[i, k]`, on every device (returned here from device 1).  Per-shard time series stay on their device and are
+read with `fetch(odef_group_ctx(g, k), ...)` exactly as in the single-GPU method -- a full gather of an every-step
+record (48.9 GB at the BASELINE size) is deliberately not part of the path.
+"""
+function solve_sharded(eprob::DiffEqBase.EnsembleProblem, alg::Union{EK0,EK1}, ealg::EnsembleHIP;
+                       trajectories::Int, u0s::Matrix{Float64}, dt=nothing, adaptive=true, abstol=1e-6, reltol=1e-3,
+                       max_steps=4096)
+    prob = eprob.prob
+    d, N = size(u0s); @assert N == trajectories
+    q = alg.order; D = d * (q + 1)
+    p = collect(Float64, prob.p)
+    cfg = Ref(OdefConfig(sizeof(OdefConfig), alg isa EK1 ? 1 : 0, q, DIFFUSIONS[alg.diffusionmodel],
+                         alg.smooth ? 1 : 0, RHS_IDS[ealg.rhs], d, length(p), 1, 1, -1, 1, N))
+    G = length(ealg.devices)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    devs = ealg.devices
+    rc = GC.@preserve devs ccall((:odef_group_create, LIB), Cint, (Ptr{Ptr{Cvoid}}, Ptr{OdefConfig}, Int32, Ptr{Int32}), h, cfg, G, devs)
+    rc == 0 || error("libodefilter_hip: " * grouperr(C_NULL))
+    g = h[]
+    try
+        t0, t1 = Float64.(prob.tspan)
+        GC.@preserve u0s p gcheck(ccall((:odef_group_set_problem, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble), g, u0s, p, t0), g)
+        if adaptive
+            gcheck(ccall((:odef_group_solve_adaptive, LIB), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Cdouble, Ptr{Cvoid}, Int64),
+                         g, t1, abstol, reltol, dt === nothing ? 1e-3 * (t1 - t0) : dt, C_NULL, max_steps), g)
+        else
+            tgrid = collect(t0:dt:t1); tgrid[end] < t1 && push!(tgrid, t1)
+            GC.@preserve tgrid gcheck(ccall((:odef_group_solve_fixed, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64), g, tgrid, length(tgrid)), g)
+        end
+        alg.smooth && gcheck(ccall((:odef_group_smooth, LIB), Cint, (Ptr{Cvoid},), g), g)
+        gcheck(ccall((:odef_allgather, LIB), Cint, (Ptr{Cvoid}, Cint), g, alg.smooth ? 1 : 0), g)   # the one collective
+        final_mean = Array{Float64}(undef, N, D)       # C layout [D][N] == Julia (N, D)
+        GC.@preserve final_mean gcheck(ccall((:odef_group_get_gathered, LIB), Cint,
+                                             (Ptr{Cvoid}, Int32, Ptr{Cdouble}, Ptr{Ptr{Cvoid}}, Ptr{Csize_t}), g, 0, final_mean, C_NULL, C_NULL), g)
+        shards = map(0:G-1) do k
+            first = Ref{Int64}(0); count = Ref{Int64}(0)
+            ccall((:odef_group_shard, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Int64}, Ptr{Int64}), g, k, first, count)
+            (first[] + 1):(first[] + count[])      # 1-based trajectory range of shard k
+        end
+        return (final_mean = final_mean, u_final = view(final_mean, :, 1:d), shards = shards)
+    finally
+        ccall((:odef_group_destroy, LIB), Cvoid, (Ptr{Cvoid},), g)
     end
 end
 
