@@ -14,6 +14,7 @@
 #include "filter_tiles.h"
 #include "rows_filter.h"
 #include "rows_smooth.h"
+#include "smooth_mfma.h"
 #include "launch.h"
 
 namespace odef {
@@ -269,13 +270,27 @@ struct LaunchTeamFilter {
     hipLaunchKernelGGL((ek_filter_team_kernel<RHS, q, EK1>), dim3((unsigned)TP.fp.N), dim3(kTeamBig), 0, s, TP);
   }
 };
+// The same pass on the matrix cores (smooth_mfma.h): 4 wavefronts per trajectory, matrices in a global workspace.
+template <int d, int q>
+__global__ __launch_bounds__(kTeamBig, 2) void rts_smooth_mfma_kernel(const SmoothParams P, double* ws) {  // two workgroups per CU: the phases are latency-bound
+  using W = MfmaSmoothWs<d, q + 1>;
+  __shared__ double lds[W::lds_size];
+  smooth_mfma_traj<d, q>(P, (long)blockIdx.x, ws + (size_t)blockIdx.x * W::size, lds);
+}
+inline bool pleiades_smooth_team() {  // ODEF_PLEIADES_SMOOTH=team: the first (vector-FMA) D = 168 smoother, for A/B comparison
+  const char* e = getenv("ODEF_PLEIADES_SMOOTH");
+  return e && e[0] == 't';
+}
 struct LaunchTeamSmooth {
   const SmoothParams& P;
   double* ws;
   hipStream_t s;
   template <int d, int q>
   void operator()() {
-    hipLaunchKernelGGL((rts_smooth_team_kernel<d, q>), dim3((unsigned)P.N), dim3(kTeamBig), 0, s, P, ws);
+    if (pleiades_smooth_team())
+      hipLaunchKernelGGL((rts_smooth_team_kernel<d, q>), dim3((unsigned)P.N), dim3(kTeamBig), 0, s, P, ws);
+    else
+      hipLaunchKernelGGL((rts_smooth_mfma_kernel<d, q>), dim3((unsigned)P.N), dim3(kTeamBig), 0, s, P, ws);
   }
 };
 

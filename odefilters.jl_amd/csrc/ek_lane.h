@@ -357,6 +357,7 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
     ++nsaved;
     if (accepted && !all_finite<D>(m)) { ret = 3; break; }
   }
+  (void)qold;
   P.loglik[i] = loglik;
   P.naccept[i] = naccept;
   P.nreject[i] = nreject;

@@ -39,11 +39,12 @@ size_t team_filter_ws_doubles(int d, int q) {
 size_t team_smooth_ws_doubles(int d, int q) {
   if (d != 28) return 0;
   switch (q) {
-    case 1: return SmoothWs<28, 2>::size;
-    case 2: return SmoothWs<28, 3>::size;
-    case 3: return SmoothWs<28, 4>::size;
-    case 4: return SmoothWs<28, 5>::size;
-    case 5: return SmoothWs<28, 6>::size;
+    // the larger of the two smoothers' workspaces (smooth_team.h: 3 D x D matrices; smooth_mfma.h: 7 padded ones)
+    case 1: return MfmaSmoothWs<28, 2>::size > (size_t)SmoothWs<28, 2>::size ? MfmaSmoothWs<28, 2>::size : (size_t)SmoothWs<28, 2>::size;
+    case 2: return MfmaSmoothWs<28, 3>::size > (size_t)SmoothWs<28, 3>::size ? MfmaSmoothWs<28, 3>::size : (size_t)SmoothWs<28, 3>::size;
+    case 3: return MfmaSmoothWs<28, 4>::size > (size_t)SmoothWs<28, 4>::size ? MfmaSmoothWs<28, 4>::size : (size_t)SmoothWs<28, 4>::size;
+    case 4: return MfmaSmoothWs<28, 5>::size > (size_t)SmoothWs<28, 5>::size ? MfmaSmoothWs<28, 5>::size : (size_t)SmoothWs<28, 5>::size;
+    case 5: return MfmaSmoothWs<28, 6>::size > (size_t)SmoothWs<28, 6>::size ? MfmaSmoothWs<28, 6>::size : (size_t)SmoothWs<28, 6>::size;
     default: return 0;
   }
 }

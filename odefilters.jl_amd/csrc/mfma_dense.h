@@ -1,0 +1,324 @@
+// Dense FP64 algebra on the matrix cores for the workgroup-per-trajectory path (D = 28 (q+1) up to 168):
+// everything is written as products of the form  C (op)= A' B  with BOTH operands "k-major" (row k of the operand matrix
+// holds the k-th term of every output row / column), because that is what v_mfma_f64_16x16x4_f64 reads coalesced:
+//
+//     D(16x16) = A(16x4) B(4x16) + C      A: lane l holds A[i = l % 16][k = l / 16]
+//                                         B: lane l holds B[k = l / 16][j = l % 16]
+//                                         C/D: lane l holds D[i = 4 v + l / 16][j = l % 16], v = 0..3
+//     (tools/mfma_layout_test.hip checks this on the hardware)
+//
+// so with P row-major and k-major, lane l of a fragment reads P[(k0 + l / 16) * ld + c0 + l % 16]: four runs of 128
+// contiguous bytes per instruction, for the A side and the B side alike.  A 16x16 accumulator tile in the D layout can
+// be fed back as the B (or A) operand of a K = 16 product without moving data: its register v IS the k-step v fragment.
+//
+//   B = U'U  (blocked Cholesky, upper factor, left-looking):   block row j of U from  B[j,:] - sum_{k<16j} U[k,j]' U[k,:]
+//            then  U[j,:] <- W_j (.)  with  W_j = L_jj^-1  the explicitly inverted 16x16 diagonal block: the panel
+//            "solve" is an MFMA product, there is no per-row substitution anywhere
+//   U'U G' = Y'  two block sweeps of the same shape (the backward one reads L = U' k-major, kept beside U)
+//   G M G'       two products with M symmetric
+//
+// Matrices are padded to DP = 16 * ceil(D / 16) with zeros (the padding block of a matrix to be factorised gets a unit
+// diagonal), so no fragment load or store is ever masked.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "team_vec.h"
+
+namespace odef {
+namespace mf {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int kB = 16;  // block size
+#ifndef ODEF_MFMA_ATB_ROWS
+#define ODEF_MFMA_ATB_ROWS 2
+#endif
+constexpr int kAtbRows = ODEF_MFMA_ATB_ROWS;  // block rows per accumulator tile set of the big products (x 3 block columns)
+
+__device__ __attribute__((always_inline)) inline int lane64() { return (int)(threadIdx.x & 63u); }
+
+// fragment of a k-major row-major operand: rows k0 .. k0+3, columns c0 .. c0+15
+__device__ __attribute__((always_inline)) inline double frag(const double* __restrict__ P, int ld, int k0, int c0) {
+  const int l = lane64();
+  return P[(size_t)(k0 + (l >> 4)) * ld + c0 + (l & 15)];
+}
+__device__ __attribute__((always_inline)) inline d4 mfma(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __attribute__((always_inline)) inline d4 zero4() { return d4{0.0, 0.0, 0.0, 0.0}; }
+
+// tile (D layout) <-> row-major memory: element (4 v + l / 16, l % 16) at P[(r0 + 4 v + l / 16) * ld + c0 + l % 16]
+__device__ __attribute__((always_inline)) inline d4 load_tile(const double* __restrict__ P, int ld, int r0, int c0) {
+  const int l = lane64();
+  d4 t;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) t[v] = P[(size_t)(r0 + 4 * v + (l >> 4)) * ld + c0 + (l & 15)];
+  return t;
+}
+__device__ __attribute__((always_inline)) inline void store_tile(double* __restrict__ P, int ld, int r0, int c0, d4 t) {
+  const int l = lane64();
+#pragma unroll
+  for (int v = 0; v < 4; ++v) P[(size_t)(r0 + 4 * v + (l >> 4)) * ld + c0 + (l & 15)] = t[v];
+}
+// the transposed tile: element (i, j) of t goes to P[(r0 + j) * ld + c0 + i]
+__device__ __attribute__((always_inline)) inline void store_tile_t(double* __restrict__ P, int ld, int r0, int c0, d4 t) {
+  const int l = lane64();
+#pragma unroll
+  for (int v = 0; v < 4; ++v) P[(size_t)(r0 + (l & 15)) * ld + c0 + 4 * v + (l >> 4)] = t[v];
+}
+
+// acc[i][j] += sum_{k in [k0, k1)} A[k][m0 + 16 i + .] * B[k][n0 + 16 j + .]   (k0, k1 multiples of 4); one wavefront
+template <int MB, int NB>
+__device__ __attribute__((always_inline)) inline void wave_atb(const double* __restrict__ A, int lda, int m0,
+                                                               const double* __restrict__ B, int ldb, int n0, int k0, int k1,
+                                                               d4 (&acc)[MB][NB]) {
+  // unrolled by two k-steps: the fragment loads of two steps (2 (MB + NB) loads) are in flight before the first product
+  // needs them (the operands stream from L2 / HBM at ~1 us latency; load-wait-MFMA iterations are latency-bound)
+#pragma unroll 2
+  for (int k = k0; k < k1; k += 4) {
+    double a[MB], b[NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) a[i] = frag(A, lda, k, m0 + kB * i);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) b[j] = frag(B, ldb, k, n0 + kB * j);
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = mfma(a[i], b[j], acc[i][j]);
+  }
+}
+// the same for one block row (m0) against NT tiles at arbitrary column offsets n0[t] (one A fragment feeds NT products)
+template <int NT>
+__device__ __attribute__((always_inline)) inline void wave_atb_cols(const double* __restrict__ A, int lda, int m0,
+                                                                    const double* __restrict__ B, int ldb, const int (&n0)[NT],
+                                                                    int k0, int k1, d4 (&acc)[NT]) {
+#pragma unroll 8
+  for (int k = k0; k < k1; k += 4) {
+    const double a = frag(A, lda, k, m0);
+    double b[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[t] = frag(B, ldb, k, n0[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma(a, b[t], acc[t]);
+  }
+}
+
+// One MB x NB block tile of  C = [Cin -] A'B  (K = kdim rows of A and B), computed and stored by one wavefront.
+template <int MB, int NB, bool SUB>
+__device__ inline void wave_atb_store(const double* __restrict__ A, int lda, int m0, const double* __restrict__ B, int ldb, int n0,
+                                      int kdim, const double* __restrict__ Cin, double* __restrict__ C, int ldc) {
+  d4 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = zero4();
+  wave_atb<MB, NB>(A, lda, m0, B, ldb, n0, 0, kdim, acc);
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      d4 t = acc[i][j];
+      if constexpr (SUB) t = load_tile(Cin, ldc, m0 + kB * i, n0 + kB * j) - t;
+      store_tile(C, ldc, m0 + kB * i, n0 + kB * j, t);
+    }
+}
+template <int NB, bool SUB>
+__device__ inline void wave_atb_rows(int mb, const double* __restrict__ A, int lda, int m0, const double* __restrict__ B, int ldb,
+                                     int n0, int kdim, const double* __restrict__ Cin, double* __restrict__ C, int ldc) {
+  if (mb == 3) wave_atb_store<3, NB, SUB>(A, lda, m0, B, ldb, n0, kdim, Cin, C, ldc);
+  else if (mb == 2) wave_atb_store<2, NB, SUB>(A, lda, m0, B, ldb, n0, kdim, Cin, C, ldc);
+  else wave_atb_store<1, NB, SUB>(A, lda, m0, B, ldb, n0, kdim, Cin, C, ldc);
+}
+// C = [Cin -] A'B over block rows [ib0, ib1) x block columns [jb0, jb1) by the wavefronts of a workgroup: strips of up
+// to 3 block columns go round-robin over the wavefronts, each strip in chunks of up to 3 block rows (9 accumulator
+// tiles per wavefront; per k-step 6 fragment loads feed 9 MFMAs; small enough for two workgroups per CU).  No two wavefronts touch the same block, so Cin may
+// alias C.
+template <bool SUB>
+__device__ inline void wg_atb(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, int kdim,
+                              const double* __restrict__ Cin, double* __restrict__ C, int ldc, int ib0, int ib1, int jb0, int jb1) {
+  const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6);
+  int strip = 0;
+  for (int jb = jb0; jb < jb1; jb += 3, ++strip) {
+    if (strip % nwaves != wave) continue;
+    const int nb = (jb1 - jb) < 3 ? (jb1 - jb) : 3;
+    for (int ib = ib0; ib < ib1; ib += kAtbRows) {
+      const int mb = (ib1 - ib) < kAtbRows ? (ib1 - ib) : kAtbRows;
+      if (nb == 3) wave_atb_rows<3, SUB>(mb, A, lda, ib * kB, B, ldb, jb * kB, kdim, Cin, C, ldc);
+      else if (nb == 2) wave_atb_rows<2, SUB>(mb, A, lda, ib * kB, B, ldb, jb * kB, kdim, Cin, C, ldc);
+      else wave_atb_rows<1, SUB>(mb, A, lda, ib * kB, B, ldb, jb * kB, kdim, Cin, C, ldc);
+    }
+  }
+}
+
+// ---- the 16 x 16 diagonal block: Cholesky D = L L' and W = L^-1, by one wavefront -------------------------------------
+// Input: the symmetric block in LDS `blk` [16][16] (lower triangle referenced).  Output: `lw` [16][16] = L (lower,
+// row-major), `w` [16][16] = W = L^-1 (lower).  Row-lane Cholesky on the first 16 lanes with DPP broadcasts (the other
+// 48 lanes of the wavefront repeat it on the same data), then lane c solves column c of L W = I against L in LDS.
+// A non-positive pivot zeroes its column (semi-definite rule of ek_math.h); its reciprocal is taken as 0.
+__device__ inline void diag_block_factor(double* __restrict__ blk, double* __restrict__ lw, double* __restrict__ w) {
+  const int r = tv::lane();
+  double row[kB];
+#pragma unroll
+  for (int c = 0; c < kB; ++c) row[c] = blk[r * kB + c];
+  double dinv_r = 0.0;  // 1 / L[r][r] of the own row
+  static_for<0, kB>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const double piv = tv::bcast<k>(row[k]);
+    const bool ok = piv > 0.0;
+    double root, rroot;
+    sqrt_and_rsqrt(ok ? piv : 1.0, root, rroot);
+    root = ok ? root : 0.0;
+    rroot = ok ? rroot : 0.0;
+    const double colk = row[k];          // lane j: D[j][k] of the current Schur complement
+    const double lik = colk * rroot;     // L[r][k] for r >= k
+    if constexpr (k + 1 < kB) tv::fb_cols<true, k + 1, kB - k - 1>(row, lik, lik);  // row[j] -= L[r][k] L[j][k], j > k
+    row[k] = lik;
+    dinv_r = (r == k) ? rroot : dinv_r;
+    (void)root;
+  });
+#pragma unroll
+  for (int c = 0; c < kB; ++c) lw[r * kB + c] = (c <= r) ? row[c] : 0.0;
+  blk[kB * kB + r] = dinv_r;  // reciprocals of the diagonal, behind the block
+  tv::lds_sync();
+  // column c = lane of W: L w = e_c, forward substitution with L read as wave-uniform LDS broadcasts
+  double wc[kB];
+#pragma unroll
+  for (int i = 0; i < kB; ++i) {
+    double t = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) t -= lw[i * kB + k] * wc[k];
+    wc[i] = t * blk[kB * kB + i];
+  }
+#pragma unroll
+  for (int i = 0; i < kB; ++i) w[i * kB + r] = (i >= r) ? wc[i] : 0.0;
+  tv::lds_sync();
+}
+
+// a-fragment of the K = 16 product  W (.)  /  W' (.)  from the 16 x 16 block W in LDS (row-major):
+//   TRANS == false:  out = W  R  ->  A'[n][k'] = W[k'][n]        TRANS == true:  out = W' R  ->  A'[n][k'] = W[n][k']
+template <bool TRANS>
+__device__ __attribute__((always_inline)) inline double wfrag(const double* __restrict__ w, int kk) {
+  const int l = lane64();
+  return TRANS ? w[(4 * kk + (l >> 4)) * kB + (l & 15)] : w[(l & 15) * kB + 4 * kk + (l >> 4)];
+}
+// out = W r  (or W' r) for a 16 x 16 tile r in the D layout: its register v is the B fragment of k-step v
+template <bool TRANS>
+__device__ __attribute__((always_inline)) inline d4 apply_w(const double* __restrict__ w, d4 r) {
+  d4 o = zero4();
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) o = mfma(wfrag<TRANS>(w, kk), r[kk], o);
+  return o;
+}
+
+// LDS layout of the factorisation scratch (doubles)
+template <int DPB>
+struct CholLds {
+  static constexpr int blk = 0;                    // 16 x 16 block + 16 reciprocals
+  static constexpr int lw = blk + kB * kB + kB;    // its factor L
+  static constexpr int w = lw + kB * kB;           // W_j = L_jj^-1, j = 0..DPB-1 (kept for the two sweeps)
+  static constexpr int size = w + DPB * kB * kB;
+};
+
+// Blocked Cholesky  B = U'U  IN PLACE in the upper triangle of Bm (full symmetric storage on entry; the lower blocks
+// are not touched), left-looking by block rows; Lm receives L = U' (lower, row-major) for the backward sweep.
+// A workgroup of 4 wavefronts; `lds`: CholLds<DPB>::size doubles.
+template <int DPB>
+__device__ inline void wg_cholesky_upper(double* __restrict__ Bm, double* __restrict__ Lm, int ld, double* __restrict__ lds) {
+  using LL = CholLds<DPB>;
+  const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6);
+  constexpr int MAXT = (DPB + 3) / 4;  // tiles of a block row per wavefront (4 wavefronts)
+  for (int j = 0; j < DPB; ++j) {
+    d4 t[MAXT];
+    // 1. tiles (j, mb), mb = j + wave, j + wave + nwaves, ...:  B[j, mb] - sum_{k < 16 j} U[k, j]' U[k, mb]
+    //    (a tile index past the last block is clamped: computed on valid memory, never stored)
+    int n0[MAXT];
+#pragma unroll
+    for (int s = 0; s < MAXT; ++s) {
+      const int mb = j + wave + s * nwaves;
+      n0[s] = (mb < DPB ? mb : DPB - 1) * kB;
+      t[s] = zero4();
+    }
+    wave_atb_cols<MAXT>(Bm, ld, j * kB, Bm, ld, n0, 0, j * kB, t);
+#pragma unroll
+    for (int s = 0; s < MAXT; ++s) {
+      const int mb = j + wave + s * nwaves;
+      if (mb < DPB) {
+        t[s] = load_tile(Bm, ld, j * kB, mb * kB) - t[s];
+        if (mb == j) {  // the diagonal block goes to LDS for the factorisation
+          const int l = lane64();
+#pragma unroll
+          for (int v = 0; v < 4; ++v) lds[LL::blk + (4 * v + (l >> 4)) * kB + (l & 15)] = t[s][v];
+        }
+      }
+    }
+    __syncthreads();
+    if (wave == 0) diag_block_factor(lds + LL::blk, lds + LL::lw, lds + LL::w + j * kB * kB);
+    __syncthreads();
+    // 2. U[j, mb] = W_j (tile);  the diagonal tile is L_jj' (its strictly lower part is rounding noise: zeroed)
+    const double* wj = lds + LL::w + j * kB * kB;
+#pragma unroll
+    for (int s = 0; s < MAXT; ++s) {
+      const int mb = j + wave + s * nwaves;
+      if (mb < DPB) {
+        d4 u = apply_w<false>(wj, t[s]);
+        if (mb == j) {
+          const int l = lane64();
+#pragma unroll
+          for (int v = 0; v < 4; ++v) u[v] = (4 * v + (l >> 4) > (l & 15)) ? 0.0 : u[v];
+        }
+        store_tile(Bm, ld, j * kB, mb * kB, u);
+        store_tile_t(Lm, ld, mb * kB, j * kB, u);
+      }
+    }
+    __syncthreads();  // block row j of U is in memory for the rows below
+  }
+}
+
+// Gt <- (U'U)^-1 Yt in place (DP x DP right-hand sides, row-major; U upper in Um, L = U' in Lm, the inverted diagonal
+// blocks in LDS from wg_cholesky_upper): forward sweep U' Z = Yt by block rows top-down, backward sweep U Gt = Z bottom-up.
+template <int DPB>
+__device__ inline void wg_solve_upper(const double* __restrict__ Um, const double* __restrict__ Lm, double* __restrict__ Yt, int ld,
+                                      const double* __restrict__ lds) {
+  using LL = CholLds<DPB>;
+  const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6);
+  constexpr int MAXT = (DPB + 3) / 4;
+  int n0[MAXT];
+#pragma unroll
+  for (int s = 0; s < MAXT; ++s) {
+    const int cb = wave + s * nwaves;
+    n0[s] = (cb < DPB ? cb : DPB - 1) * kB;
+  }
+  for (int j = 0; j < DPB; ++j) {  // Z_j = W_j (Yt_j - sum_{k < 16 j} U[k, j]' Z[k, :])
+    const double* wj = lds + LL::w + j * kB * kB;
+    d4 acc[MAXT];
+#pragma unroll
+    for (int s = 0; s < MAXT; ++s) acc[s] = zero4();
+    wave_atb_cols<MAXT>(Um, ld, j * kB, Yt, ld, n0, 0, j * kB, acc);
+#pragma unroll
+    for (int s = 0; s < MAXT; ++s) {
+      const int cb = wave + s * nwaves;
+      if (cb < DPB) {
+        const d4 r = load_tile(Yt, ld, j * kB, cb * kB) - acc[s];
+        store_tile(Yt, ld, j * kB, cb * kB, apply_w<false>(wj, r));
+      }
+    }
+    __syncthreads();
+  }
+  for (int j = DPB - 1; j >= 0; --j) {  // Gt_j = W_j' (Z_j - sum_{k >= 16 (j+1)} L[k, j]' Gt[k, :])
+    const double* wj = lds + LL::w + j * kB * kB;
+    d4 acc[MAXT];
+#pragma unroll
+    for (int s = 0; s < MAXT; ++s) acc[s] = zero4();
+    wave_atb_cols<MAXT>(Lm, ld, j * kB, Yt, ld, n0, (j + 1) * kB, DPB * kB, acc);
+#pragma unroll
+    for (int s = 0; s < MAXT; ++s) {
+      const int cb = wave + s * nwaves;
+      if (cb < DPB) {
+        const d4 r = load_tile(Yt, ld, j * kB, cb * kB) - acc[s];
+        store_tile(Yt, ld, j * kB, cb * kB, apply_w<true>(wj, r));
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace mf
+}  // namespace odef

@@ -1,0 +1,262 @@
+// RTS smoother for the workgroup-per-trajectory path (Pleiades, D = 28 (q+1) up to 168) ON THE MATRIX CORES:
+// the whole step of src/smoothing.jl:31-63 is dense D x D algebra, and every O(D^3) part of it runs as
+// v_mfma_f64_16x16x4_f64 products (csrc/mfma_dense.h):
+//
+//   X = P Sigma_i P                     unpack the packed record (full symmetric, padded to DP = 16 ceil(D/16))
+//   Yt = A X,  B = Yt-rows A' + sigma^2 Q   the prior is A = At (x) I_d: block-row / block-column combinations, O(D^2 q)
+//   M = P Sigma^s_{i+1} P - B
+//   B = U'U                             blocked Cholesky, block row = MFMA product against the explicitly inverted 16 x 16
+//                                       diagonal block (no per-row substitution)                    [D^3 / 3 flops]
+//   Gt = (U'U)^-1 Yt                    two block sweeps, again only products                       [2 D^3]
+//   m^s = m + G (m^s_{i+1} - A m)
+//   Sigma^s = X + G M G'                two products Z = M Gt, R = Z' Gt (M symmetric)               [4 D^3]
+//
+// The first version of this smoother (csrc/smooth_team.h, kept as ODEF_PLEIADES_SMOOTH=team for A/B and as what the
+// host emulation runs) does the same algebra with 7 x 7 register tiles of vector FMAs and per-row substitutions out of
+// a global workspace: 1.57e5 steps/s.  The textbook form X + G (S^s_+ - S^-) G' is the identity the reference's own test
+// asserts for its stacked-QR Joseph form (test/filtering.jl:113).
+//
+// One workgroup of 256 threads (4 wavefronts) per trajectory; matrices in a per-trajectory global workspace
+// (7 DP^2 doubles, L2 / Infinity-Cache resident while in use), vectors and the inverted diagonal blocks in LDS.
+#pragma once
+#include "ek_lane.h"
+#include "mfma_dense.h"
+
+namespace odef {
+
+#ifdef ODEF_MFMA_STAMPS  // diagnostic build (tools/mfma_smooth_stamps.hip): cycles per phase of workgroup 0
+__device__ unsigned long long g_mfma_stamps[16];
+#define ODEF_STAMP(k)                                                          \
+  do {                                                                         \
+    __syncthreads();                                                           \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                 \
+      const unsigned long long now_ = wall_clock64();                          \
+      g_mfma_stamps[k] += now_ - stamp_t0_;                                    \
+      stamp_t0_ = now_;                                                        \
+    }                                                                          \
+  } while (0)
+#else
+#define ODEF_STAMP(k)
+#endif
+
+template <int d, int NB>
+struct MfmaSmoothWs {
+  static constexpr int D = d * NB, DPB = (D + 15) / 16, DP = DPB * 16, MAT = DP * DP;
+  static constexpr int X = 0, YT = MAT, BM = 2 * MAT, LM = 3 * MAT, MM = 4 * MAT, Z2 = 5 * MAT, SG = 6 * MAT;
+  static constexpr size_t size = 7 * (size_t)MAT;
+  // LDS (doubles): factorisation scratch, then the vectors
+  static constexpr int kChol = mf::CholLds<DPB>::size;
+  static constexpr int MF = kChol, MS = MF + DP, MP = MS + DP, DL = MP + DP, PJ = DL + DP, PIJ = PJ + DP;
+  static constexpr int lds_size = PIJ + DP;
+};
+
+// (a, b) of packed lower-triangle element e, advanced by `step` elements at a time without square roots
+struct TriWalk {
+  int a, b;
+  __device__ inline TriWalk(int e) {
+    a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+    while (a * (a + 1) / 2 > e) --a;
+    while ((a + 1) * (a + 2) / 2 <= e) ++a;
+    b = e - a * (a + 1) / 2;
+  }
+  __device__ inline void advance(int step) {
+    b += step;
+    while (b > a) {
+      b -= a + 1;
+      ++a;
+    }
+  }
+};
+
+template <int d, int q>
+__device__ inline void smooth_mfma_traj(const SmoothParams& P, long i, double* __restrict__ ws, double* __restrict__ lds) {
+  constexpr int NB = q + 1;
+  using W = MfmaSmoothWs<d, NB>;
+  constexpr int D = W::D, DP = W::DP, DPB = W::DPB, TRI = D * (D + 1) / 2;
+  const int tid = (int)threadIdx.x, nth = (int)blockDim.x;
+  const long n = P.adaptive ? (long)P.nsaved[i] : P.n_save;
+  const size_t N = (size_t)P.N;
+  const PriorConsts& pc = P.pc;
+  double* X = ws + W::X;
+  double* YT = ws + W::YT;
+  double* BM = ws + W::BM;
+  double* LM = ws + W::LM;
+  double* MM = ws + W::MM;
+  double* Z2 = ws + W::Z2;
+  double* SG = ws + W::SG;
+  double* mf_ = lds + W::MF;
+  double* ms_ = lds + W::MS;
+  double* mp_ = lds + W::MP;
+  double* dl_ = lds + W::DL;
+  double* pj_ = lds + W::PJ;
+  double* pij_ = lds + W::PIJ;
+
+  // zero the workspace once (padding rows / columns stay zero from here on); L = U' must be zero above the diagonal
+  for (size_t e = tid; e < W::size; e += nth) ws[e] = 0.0;
+  __syncthreads();
+  // first and last record are copied (index 1 in Julia is never smoothed, src/smoothing.jl:11); the last one is the
+  // carried smoothed state Sigma^s (SG, full symmetric, un-preconditioned)
+  for (int w = 0; w < 2; ++w) {
+    const long s = w == 0 ? 0 : n - 1;
+    for (int k = tid; k < D; k += nth) {
+      const double v = P.mean[((size_t)s * D + k) * N + i];
+      P.smean[((size_t)s * D + k) * N + i] = v;
+      ms_[k] = v;
+    }
+    TriWalk tw(tid);
+    for (int e = tid; e < TRI; e += nth, tw.advance(nth)) {
+      const double v = P.cov[((size_t)s * TRI + e) * N + i];
+      P.scov[((size_t)s * TRI + e) * N + i] = v;
+      SG[tw.a * DP + tw.b] = v;
+      SG[tw.b * DP + tw.a] = v;
+    }
+  }
+  __syncthreads();
+  bool nan_seen = false;
+#ifdef ODEF_MFMA_STAMPS
+  unsigned long long stamp_t0_ = wall_clock64();
+#endif
+  for (long s = n - 2; s >= 1; --s) {
+    double h;
+    if (P.adaptive) h = P.tsave[(size_t)(s + 1) * N + i] - P.tsave[(size_t)s * N + i];
+    else h = uniform_load(P.hs + s);
+    if (h == 0.0) {  // src/smoothing.jl:13-16: a repeated save time, the smoothed state carries over
+      for (int k = tid; k < D; k += nth) P.smean[((size_t)s * D + k) * N + i] = ms_[k];
+      for (int e = tid; e < TRI; e += nth) P.scov[((size_t)s * TRI + e) * N + i] = P.scov[((size_t)(s + 1) * TRI + e) * N + i];
+      __syncthreads();
+      continue;
+    }
+    // preconditioner of this step (src/preconditioning.jl:1-17), per state component
+    if (tid < DP) {
+      double pj = 0.0, pij = 0.0;
+      if (tid < D) {
+        if (P.adaptive) {
+          double tabv[kTabStride];
+          precond_table_fast<q, NB>(h, tabv);
+          pj = tabv[kTabPJ + tid / d];
+          pij = tabv[kTabPIJ + tid / d];
+        } else {
+          const GlobalTab tab{P.ptab + (size_t)uniform_load(P.tab_idx + s) * kTabStride};
+          pj = tab[kTabPJ + tid / d];
+          pij = tab[kTabPIJ + tid / d];
+        }
+      }
+      pj_[tid] = pj;
+      pij_[tid] = pij;
+    }
+    const double sigma2 = P.diff[(size_t)(s + 1) * N + i];
+    __syncthreads();
+    // X = P Sigma_i P (src/smoothing.jl:23), m~ = P m_i
+    {
+      TriWalk tw(tid);
+      const double* src = P.cov + ((size_t)s * TRI) * N + i;
+#pragma unroll 4
+      for (int e = tid; e < TRI; e += nth, tw.advance(nth)) {
+        const double v = src[(size_t)e * N] * (pj_[tw.a] * pj_[tw.b]);
+        X[tw.a * DP + tw.b] = v;
+        X[tw.b * DP + tw.a] = v;
+      }
+    }
+    for (int k = tid; k < D; k += nth) mf_[k] = pj_[k] * P.mean[((size_t)s * D + k) * N + i];
+    __syncthreads();
+    ODEF_STAMP(0);  // unpack
+    // Yt = A X (row (J, a) picks up the rows (j, a), j > J);  m^- = A m~ (src/filtering.jl:22-25)
+    // one work item = (component a, column c): the NB rows (j, a) of X in that column give all NB rows (J, a) of Yt
+    for (int e = tid; e < d * DP; e += nth) {
+      const int a = e / DP, c = e % DP;
+      double x[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) x[j] = X[(j * d + a) * DP + c];
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        double t = x[J];
+#pragma unroll
+        for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * x[j];
+        YT[(J * d + a) * DP + c] = t;
+      }
+    }
+    for (int k = tid; k < D; k += nth) {
+      const int J = k / d, a = k % d;
+      double t = mf_[k];
+      for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * mf_[j * d + a];
+      mp_[k] = t;
+    }
+    __syncthreads();
+    ODEF_STAMP(1);  // Yt
+    // B = A X A' + sigma^2 Q (src/filtering.jl:34-35) from the rows of Yt;  M = P Sigma^s_+ P - B;  delta
+    // one work item = (row r, component b): the NB entries (k, b) of row r of Yt give all NB entries (K, b) of row r of B
+    for (int e = tid; e < D * d; e += nth) {
+      const int r = e / d, b = e % d;
+      double yv[NB], sg[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        yv[k] = YT[r * DP + k * d + b];
+        sg[k] = SG[r * DP + k * d + b];
+      }
+      const bool diag = (r % d) == b;
+      const int J = r / d;
+#pragma unroll
+      for (int K = 0; K < NB; ++K) {
+        double bv = yv[K];
+#pragma unroll
+        for (int k = K + 1; k < NB; ++k) bv += pc.At[K][k] * yv[k];
+        double qv = 0.0;
+#pragma unroll
+        for (int JJ = 0; JJ < NB; ++JJ) qv = (JJ == J) ? pc.Qt[JJ][K] : qv;
+        if (diag) bv += sigma2 * qv;
+        const int c = K * d + b;
+        BM[r * DP + c] = bv;
+        MM[r * DP + c] = sg[K] * (pj_[r] * pj_[c]) - bv;
+      }
+    }
+    // the padding block of B is the identity (R of the previous step left zeros there); M is zero there from the start
+    for (int e = tid; e < (DP - D) * DP; e += nth) {
+      const int r = D + e / DP, c = e % DP;
+      BM[r * DP + c] = (r == c) ? 1.0 : 0.0;
+      BM[c * DP + r] = (r == c) ? 1.0 : 0.0;
+    }
+    for (int k = tid; k < D; k += nth) dl_[k] = pj_[k] * ms_[k] - mp_[k];
+    __syncthreads();
+    ODEF_STAMP(2);  // B, M
+    // B = U'U, Gt = B^-1 Yt (the gain G = X A' (Sigma^-)^-1, src/smoothing.jl:42-43, transposed)
+    mf::wg_cholesky_upper<DPB>(BM, LM, DP, lds);
+    ODEF_STAMP(3);  // Cholesky
+    mf::wg_solve_upper<DPB>(BM, LM, YT, DP, lds);
+    ODEF_STAMP(4);  // sweeps
+    // m^s = m + G delta (src/smoothing.jl:44), un-preconditioned (:26)
+    for (int k = tid; k < D; k += nth) {
+      double t = mf_[k];
+#pragma unroll 8
+      for (int r = 0; r < D; ++r) t += YT[r * DP + k] * dl_[r];
+      const double v = t * pij_[k];
+      nan_seen = nan_seen || !(v == v);
+      ms_[k] = v;
+      P.smean[((size_t)s * D + k) * N + i] = v;
+    }
+    // Z = M Gt, R = Z' Gt = G M G'
+    ODEF_STAMP(5);  // mean
+    mf::wg_atb<false>(MM, DP, YT, DP, DP, nullptr, Z2, DP, 0, DPB, 0, DPB);
+    __syncthreads();
+    ODEF_STAMP(6);  // Z = M Gt
+    mf::wg_atb<false>(Z2, DP, YT, DP, DP, nullptr, BM, DP, 0, DPB, 0, DPB);
+    __syncthreads();
+    ODEF_STAMP(7);  // R = Z' Gt
+    // Sigma^s = P^-1 (X + G M G') P^-1: the record (packed lower triangle) and the carried full matrix
+    {
+      TriWalk tw(tid);
+      double* dst = P.scov + ((size_t)s * TRI) * N + i;
+#pragma unroll 4
+      for (int e = tid; e < TRI; e += nth, tw.advance(nth)) {
+        const double v = (X[tw.a * DP + tw.b] + BM[tw.a * DP + tw.b]) * (pij_[tw.a] * pij_[tw.b]);
+        dst[(size_t)e * N] = v;
+        SG[tw.a * DP + tw.b] = v;
+        SG[tw.b * DP + tw.a] = v;
+      }
+    }
+    __syncthreads();
+    ODEF_STAMP(8);  // pack + store
+  }
+  if (nan_seen) P.retcode[i] = 3;  // "NaNs after smoothing" (src/smoothing.jl:25)
+}
+
+}  // namespace odef
