@@ -232,22 +232,22 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
   const long n = ADAPT ? (long)P.nsaved[i] : P.n_save;
   const size_t N = (size_t)P.N;
   const PriorConsts& pc = P.pc;
-  // The smoothed covariance of time i+1 is NOT carried in registers: it is re-read from the record
-  // written one iteration earlier (L2-resident), which keeps the live set at two packed matrices.
-  double ms[D];
+  // The smoothed moments of time s+1 are CARRIED in registers (un-preconditioned, exactly the values stored): every
+  // record is read once and written once.  (Until round 2 the covariance was re-read from the record written one
+  // iteration earlier, 1.5 x the algorithmic traffic: profiles/r01_smoother_lane_pmc.json.)
+  double ms[D], Sn[TRI];
   for (int w = 0; w < 2; ++w) {  // first and last record are copied (src/smoothing.jl:11)
     const long s = w == 0 ? 0 : n - 1;
     {
-      double tmp[TRI];  // all loads in flight before the first store
       const double* src = P.cov + ((size_t)s * TRI) * N + i;
 #pragma unroll
-      for (int k = 0; k < TRI; ++k) tmp[k] = src[(size_t)k * N];
+      for (int k = 0; k < TRI; ++k) Sn[k] = src[(size_t)k * N];  // all loads in flight before the first store
 #pragma unroll
       for (int k = 0; k < D; ++k) ms[k] = P.mean[((size_t)s * D + k) * N + i];
       ODEF_SCHED_FENCE();
       double* dst = P.scov + ((size_t)s * TRI) * N + i;
 #pragma unroll
-      for (int k = 0; k < TRI; ++k) dst[(size_t)k * N] = tmp[k];
+      for (int k = 0; k < TRI; ++k) dst[(size_t)k * N] = Sn[k];
 #pragma unroll
       for (int k = 0; k < D; ++k) P.smean[((size_t)s * D + k) * N + i] = ms[k];
     }
@@ -255,7 +255,10 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
   bool nan_seen = false;
   // The slot index walks the same value in every lane but is deliberately kept in a VGPR: with a scalar slot
   // the compiler moves the record address arithmetic to the SALU (s_mul chains, SGPR spills, hazard nops in
-  // front of the loads) and the fixed-grid smoother measured 44 ms instead of 39 ms.
+  // front of the loads) and the fixed-grid smoother measured 44 ms instead of 39 ms.  (Round 2 tried the other
+  // extreme as well -- wave-uniform row bases advanced by s_add_u32 / s_addc_u32 and raw buffer accesses with a
+  // constant lane offset: 616 fewer VALU address instructions, but as many scalar ones, and a lone wavefront per SIMD
+  // pays one issue slot for either kind: 36 -> 60 ms with the spills that came with it.)
   long s_start = n_hi - 2;
 #ifndef ODEF_HOST_EMUL
   {
@@ -266,7 +269,7 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
 #endif
   for (long s = s_start; s >= 1; --s) {
     if constexpr (ADAPT) {
-      if (s > n - 2) continue;  // this trajectory has fewer records: it joins at its own last one
+      if (s > n - 2) continue;  // this trajectory has fewer records: it joins at its own last one (ms, Sn hold it)
     }
     double h, pj[NB], pij[NB];
     if constexpr (ADAPT) {
@@ -291,28 +294,22 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
 #pragma unroll
       for (int k = 0; k < D; ++k) P.smean[((size_t)s * D + k) * N + i] = ms[k];
 #pragma unroll
-      for (int k = 0; k < TRI; ++k) P.scov[((size_t)s * TRI + k) * N + i] = P.scov[((size_t)(s + 1) * TRI + k) * N + i];
+      for (int k = 0; k < TRI; ++k) P.scov[((size_t)s * TRI + k) * N + i] = Sn[k];
       continue;
     }
     const double sigma2 = P.diff[(size_t)(s + 1) * N + i];
     // x_i and x_{i+1}^s in preconditioned coordinates (src/smoothing.jl:23-24)
-    // Phase 1: every load of the step in flight (raw values, running pointers, no arithmetic in between:
-    // a spill reload between two loads would make the compiler wait for the first one -- scratch and global
-    // loads share vmcnt -- and serialise 160 memory latencies per step).  Phase 2: scale.
+    // Phase 1: every load of the step in flight (raw values, no arithmetic in between: a spill reload between two
+    // loads would make the compiler wait for the first one -- scratch and global loads share vmcnt -- and serialise
+    // the memory latencies of the step).  Phase 2: scale.
     double mt[D], B[TRI], Cs[TRI];
     {
       const double* pc_ = P.cov + ((size_t)s * TRI) * N + i;
-      const double* ps_ = P.scov + ((size_t)(s + 1) * TRI) * N + i;
       const double* pm_ = P.mean + ((size_t)s * D) * N + i;
 #pragma unroll
       for (int k = 0; k < TRI; ++k) {
         B[k] = *pc_;
         pc_ += N;
-      }
-#pragma unroll
-      for (int k = 0; k < TRI; ++k) {
-        Cs[k] = *ps_;
-        ps_ += N;
       }
 #pragma unroll
       for (int k = 0; k < D; ++k) {
@@ -331,12 +328,15 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
         const double x = B[tri(a, b)] * pp;
         xl.set(tri(a, b), x);
         B[tri(a, b)] = x;
-        Cs[tri(a, b)] *= pp;
+        Cs[tri(a, b)] = Sn[tri(a, b)] * pp;
       }
     double msn[D], msnew[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) msn[k] = pj[k / d] * ms[k];
-    auto sink = [&](int k, double v) { P.scov[((size_t)s * TRI + k) * N + i] = v; };
+    auto sink = [&](int k, double v) {
+      Sn[k] = v;
+      P.scov[((size_t)s * TRI + k) * N + i] = v;
+    };
     rts_step_core<d, NB>(pc, pij, mt, B, Cs, msn, sigma2, xl, msnew, sink);
 #pragma unroll
     for (int k = 0; k < D; ++k) ms[k] = msnew[k];
