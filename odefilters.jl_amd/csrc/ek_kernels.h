@@ -12,6 +12,7 @@
 #include "sample_lane.h"
 #include "filter_team.h"
 #include "filter_tiles.h"
+#include "filter_mfma.h"
 #include "rows_filter.h"
 #include "rows_smooth.h"
 #include "smooth_mfma.h"
@@ -249,12 +250,22 @@ __global__ __launch_bounds__(kTilesBlock) void ek_filter_tiles_adaptive_kernel(c
   else
     TF::template run_adaptive<false>(P, (long)blockIdx.x, (int)threadIdx.x, sm, &st);
 }
+// ODEF_PLEIADES_FILTER=tiles selects the register-tiled VALU kernel for fixed-step solves too (default: the MFMA
+// kernel of filter_mfma.h; adaptive solves always run on the tiled kernel)
+inline bool pleiades_filter_tiles() {
+  const char* e = getenv("ODEF_PLEIADES_FILTER");
+  return e && e[0] == 't';
+}
 struct LaunchTilesFilter {
   const FilterParams& P;
   hipStream_t s;
   int adaptive = 0;
   template <class RHS, int q, bool EK1>
   void operator()() {
+    if (!adaptive && !pleiades_filter_tiles()) {
+      hipLaunchKernelGGL((ek_filter_mfma_kernel<RHS, q, EK1>), dim3((unsigned)P.N), dim3(kMfBlock), 0, s, P);
+      return;
+    }
     if (adaptive)
       hipLaunchKernelGGL((ek_filter_tiles_adaptive_kernel<RHS, q, EK1>), dim3((unsigned)P.N), dim3(kTilesBlock), 0, s, P);
     else

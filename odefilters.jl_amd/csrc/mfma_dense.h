@@ -153,7 +153,7 @@ __device__ inline void wg_atb(const double* __restrict__ A, int lda, const doubl
 // row-major), `w` [16][16] = W = L^-1 (lower).  Row-lane Cholesky on the first 16 lanes with DPP broadcasts (the other
 // 48 lanes of the wavefront repeat it on the same data), then lane c solves column c of L W = I against L in LDS.
 // A non-positive pivot zeroes its column (semi-definite rule of ek_math.h); its reciprocal is taken as 0.
-__device__ inline void diag_block_factor(double* __restrict__ blk, double* __restrict__ lw, double* __restrict__ w) {
+__device__ inline void diag_block_factor(double* __restrict__ blk, double* __restrict__ lw, double* __restrict__ w, int ldw = kB) {
   const int r = tv::lane();
   double row[kB];
 #pragma unroll
@@ -188,7 +188,7 @@ __device__ inline void diag_block_factor(double* __restrict__ blk, double* __res
     wc[i] = t * blk[kB * kB + i];
   }
 #pragma unroll
-  for (int i = 0; i < kB; ++i) w[i * kB + r] = (i >= r) ? wc[i] : 0.0;
+  for (int i = 0; i < kB; ++i) w[i * ldw + r] = (i >= r) ? wc[i] : 0.0;
   tv::lds_sync();
 }
 
