@@ -14,17 +14,20 @@
 // second stage removes exactly that residual.  In float64 this recursion stays as close to the extended-precision
 // evaluation of the reference algorithm as the reference's own square-root arithmetic.
 // Every D-sized operation is a rank-d product -- 2 d D^2 flops each, on the matrix pipe -- and there is no D-sized
-// factorisation, no Householder QR and no per-pivot synchronisation of the workgroup: the step has 17 barriers instead
+// factorisation, no Householder QR and no per-pivot synchronisation of the workgroup: the step has 16 barriers instead
 // of ~45 (filter_tiles.h, which stays in the library: adaptive solves, ODEF_PLEIADES_FILTER=tiles).
 //
 // Tiles.  Each derivative block (d = 28 rows) is split into two tiles of 14 real rows + 2 zero rows, so that the
 // Kronecker congruence maps whole tiles onto whole tiles (tile 2 b + h <-> rows 14 h .. 14 h + 13 of block b) and
 // DP = 32 (q + 1) = 192 at order 5.  Only tiles (Q, P) with Q <= P are kept (78 of them): tile column P belongs to ONE
-// wavefront (columns are dealt to the 8 wavefronts by decreasing size, 9-12 tiles each), in the accumulator layout
+// wavefront (columns are dealt to 7 wavefronts by decreasing size: 12, 11, 11, 11, 11, 11, 11 tiles), in the accumulator layout
 //     register v of lane l  <->  element (row 4 v + l / 16, column l % 16).
 // A tile in this layout IS the B operand of a K = 16 product (register v = k-step v), so  H (.) tile  needs no data
 // movement; products that need the tile as the A operand (the six tiles above the diagonal of the first two derivative
 // blocks) go through a small LDS copy.  The rank-d updates read their D x d operand panels (V, K, E) from LDS.
+// The eighth wavefront owns no tile: it runs the two d x d factorisations (H Q H' for sigma^2 -- beside the congruence
+// of the others: sigma^2 Q is added to the tiles and sigma^2 Q H' to the panel only after C = (A S A') H' is there -- and
+// Sm, which everybody waits for).
 #pragma once
 #ifndef ODEF_HOST_EMUL
 #include "ek_lane.h"
@@ -34,46 +37,83 @@
 
 namespace odef {
 
-constexpr int kMfWaves = 8;
+constexpr int kMfWaves = 9;       // wavefronts of the workgroup
+constexpr int kMfTileWaves = 8;   // ... that own tiles; the last one is the helper
+constexpr int kMfHelper = 8;
 constexpr int kMfBlock = 64 * kMfWaves;
 
-// tile ownership: columns by decreasing size to the least loaded wavefront; slots of a column are contiguous, Q ascending
+// In-kernel stamps at phase boundaries: ONLY in the diagnostic build of tools/mfma_filter_stamps.hip
+// (-DODEF_MF_STAMPS); the product kernel contains none.
+#ifdef ODEF_MF_STAMPS
+__device__ unsigned long long* g_mf_stamp_buf = nullptr;
+__device__ unsigned long long g_mf_stamp_last = 0;
+#define ODEF_MF_STAMP(k)                                                      \
+  if (tid == 0 && blockIdx.x == 0 && g_mf_stamp_buf) {                        \
+    unsigned long long t_;                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    g_mf_stamp_buf[(k)] += t_ - g_mf_stamp_last;                              \
+    g_mf_stamp_last = t_;                                                     \
+  }
+#else
+#define ODEF_MF_STAMP(k)
+#endif
+
+// Tile ownership.  The "head" of a tile column (its tiles in the first four tile rows: the ones H (.) reads) stays in
+// one wavefront, so that C = S^- H' needs no reduction across wavefronts; every other tile may go anywhere.  Heads are
+// dealt first (largest column first, to the least loaded wavefront), then the remaining tiles column by column, each to
+// the least loaded wavefront (staying with the previous tile's wavefront while that one is below the average load, so
+// that the B fragments of a column are reloaded rarely).  78 tiles over 8 wavefronts: 10, 10, 10, 10, 10, 10, 9, 9.
 template <int NT>
 struct MfOwnTab {
-  int n[kMfWaves];
-  int Q[kMfWaves][NT];
-  int P[kMfWaves][NT];
-  int helper;  // least loaded wavefront: it also runs the two small sequential factorisations
+  static constexpr int ntiles = NT * (NT + 1) / 2;
+  static constexpr int cap = (ntiles + kMfTileWaves - 1) / kMfTileWaves + 3;  // upper bound of a wavefront's load
+  int n[kMfTileWaves];
+  int Q[kMfTileWaves][cap];
+  int P[kMfTileWaves][cap];
+  int maxload;
   bool ok;
 };
 template <int NT>
 constexpr MfOwnTab<NT> make_mf_own() {
   MfOwnTab<NT> t{};
+  constexpr int cap = MfOwnTab<NT>::cap, target = (MfOwnTab<NT>::ntiles + kMfTileWaves - 1) / kMfTileWaves;
   t.ok = true;
-  for (int w = 0; w < kMfWaves; ++w) {
+  for (int w = 0; w < kMfTileWaves; ++w) {
     t.n[w] = 0;
-    for (int s = 0; s < NT; ++s) {
+    for (int s = 0; s < cap; ++s) {
       t.Q[w][s] = -1;
       t.P[w][s] = -1;
     }
   }
-  for (int P = NT - 1; P >= 0; --P) {
+  auto least = [&]() {
     int w = 0;
-    for (int k = 1; k < kMfWaves; ++k)
+    for (int k = 1; k < kMfTileWaves; ++k)
       if (t.n[k] < t.n[w]) w = k;
-    if (t.n[w] + P + 1 > NT) {
-      t.ok = false;
-      break;
-    }
-    for (int Q = 0; Q <= P; ++Q) {
+    return w;
+  };
+  for (int P = NT - 1; P >= 0; --P) {  // heads
+    const int w = least();
+    for (int Q = 0; Q <= (P < 3 ? P : 3); ++Q) {
+      if (t.n[w] >= cap) { t.ok = false; return t; }
       t.Q[w][t.n[w]] = Q;
       t.P[w][t.n[w]] = P;
       ++t.n[w];
     }
   }
-  t.helper = 0;
-  for (int k = 1; k < kMfWaves; ++k)
-    if (t.n[k] < t.n[t.helper]) t.helper = k;
+  int prev = -1;
+  for (int P = NT - 1; P >= 4; --P)
+    for (int Q = 4; Q <= P; ++Q) {
+      int w = least();
+      if (prev >= 0 && t.n[prev] < target) w = prev;
+      if (t.n[w] >= cap) { t.ok = false; return t; }
+      t.Q[w][t.n[w]] = Q;
+      t.P[w][t.n[w]] = P;
+      ++t.n[w];
+      prev = w;
+    }
+  t.maxload = 0;
+  for (int w = 0; w < kMfTileWaves; ++w)
+    if (t.n[w] > t.maxload) t.maxload = t.n[w];
   return t;
 }
 
@@ -87,18 +127,25 @@ struct MfLds {
   static constexpr int VP = 0, KP = VP + DP * LDP, TL = KP + DP * LDP;  // TL: 6 tiles above the diagonal + 4 diagonal ones
   static constexpr int R0_need = TL + 10 * 256;
   static constexpr int R0_size = EX_size > R0_need ? EX_size : R0_need;
-  // region B, time-shared: raw / scaled Jacobian block H0, M0, W = H Q H'  |  W_S = L^-1 of the innovation covariance
-  // and the scratch of its blocked factorisation
+  // region B, time-shared:
+  //   H0 | M0 | WM          raw / scaled Jacobian block, M0, W = H Q H'           (measure ... chol(W))
+  //   scratch of chol(W)    over H0 | M0 once W is built: two diagonal blocks (+ pivots), the block below, L21, W11, W22
+  //   WL | scratch of Sm    W_S = L^-1 of the innovation covariance [32][LDP], then the blocks of Sm and L21
   static constexpr int LDd = d + 1;
   static constexpr int H0 = R0_size, M0 = H0 + d * d, WM = M0 + d * d;
-  static constexpr int WL = R0_size, SB11 = WL + 32 * LDP, SB22 = SB11 + 272, SB21 = SB22 + 272, LW = SB21 + 256, L21 = LW + 256;
+  static constexpr int CW11 = R0_size, CW22 = CW11 + 272, CW21 = CW22 + 272, CWL = CW21 + 256, CWW1 = CWL + 256, CWW2 = CWW1 + 256;
+  static_assert(CWW2 + 256 <= WM, "the scratch of chol(W) must not reach W itself");
+  static constexpr int WL = R0_size, SB11 = WL + 32 * LDP, SB22 = SB11 + 272, SB21 = SB22 + 272, L21 = SB21 + 256;
   static constexpr int B_need1 = 2 * d * d + d * LDd, B_need2 = L21 + 256 - R0_size;
   static constexpr int B_size = B_need1 > B_need2 ? B_need1 : B_need2;
   static constexpr int HS0 = R0_size + B_size;  // [32][LDP]: H0' in padded indices (k = state column, a = measurement)
-  static constexpr int MV = HS0 + 32 * LDP, MT = MV + D, MP = MT + D, Z = MP + D, ZP = Z + d, YV = ZP + 32, UP = YV + 32;
+  static constexpr int MV = HS0 + 32 * LDP, MT = MV + D, MP = MT + D, Z = MP + D, YV = Z + 32, UP = YV + 32;  // z: d values + zeros up to 32
   static constexpr int DU = UP + d, WD = DU + d, UC = WD + d, SC = UC + d, CTL = SC + 8, TAB = CTL + 8;
-  static constexpr int size = TAB + kTabStride;
+  static constexpr int CF1 = TAB + kTabStride, CF2 = CF1 + NB * NB * NB;  // coefficients of the two congruence stages
+  static constexpr int size = CF2 + NB * NB;
   static_assert(d % 2 == 0 && d / 2 <= 16 && d / 2 >= 1, "a derivative block is split into two tiles of d / 2 <= 16 rows");
+  static constexpr int DUMMY = EX_size;  // 64 doubles behind the exchange: where the padding lanes of a tile store go
+  static_assert(R0_size >= EX_size + 64, "room for the dummy stores");
   static_assert(size * 8 <= 160 * 1024, "LDS budget of one workgroup");
 };
 
@@ -108,18 +155,37 @@ struct MfmaFilter {
   using W = MfLds<d, NB>;
   using d4 = mf::d4;
   static constexpr int NT = W::NT, TR = W::TR, TSZ = W::TSZ, LDP = W::LDP, NTHR = kMfBlock;
-  static constexpr MfOwnTab<NT> own = make_mf_own<NT>();
-  static constexpr int kHelper = make_mf_own<NT>().helper;
+  static constexpr int NS = make_mf_own<NT>().maxload;  // tile slots per wavefront
+  static constexpr int kHelper = kMfHelper;
   static_assert(make_mf_own<NT>().ok, "tile columns do not fit the slot table");
 
   struct Geo {  // per-lane geometry of the accumulator layout
-    int g, j;
+    int g, j, lane;
     bool ok[4];  // element (4 v + g, j) is a real entry of its tile
     int sym[4];  // offset of element (min, max) of (4 v + g, j) in a compact TR x TR tile: upper-triangle read of a diagonal tile
   };
   struct Slots {
-    int tq[NT], tp[NT];  // wave-uniform tile coordinates of slot s (-1: unused)
+    int tq[NS], tp[NS];  // wave-uniform tile coordinates of slot s (-1: unused)
   };
+  // The lane geometry is loop-invariant, and so is every LDS address derived from it: left alone, the compiler hoists a few
+  // hundred of them out of the step loop, runs out of registers and reloads them from scratch inside the phases
+  // (scratch loads share vmcnt with nothing else here, but they sit on the critical path of every phase).  Each phase
+  // therefore starts from a laundered copy -- no instructions, the values just stop being provably invariant.
+  __device__ __attribute__((always_inline)) static inline Geo fresh(const Geo& G0) {
+    Geo G;
+    int g = G0.g, j = G0.j, lane = G0.lane;
+    asm volatile("" : "+v"(g), "+v"(j), "+v"(lane));
+    G.g = g;
+    G.j = j;
+    G.lane = lane;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int i = 4 * v + g;
+      G.ok[v] = (i < TR) && (j < TR);
+      G.sym[v] = (i < j ? i : j) * TR + (i < j ? j : i);
+    }
+    return G;
+  }
 
 #define ODEF_MF_FN __device__ __attribute__((always_inline)) static inline
 
@@ -128,18 +194,18 @@ struct MfmaFilter {
 
   // tile <-> compact exchange slot
   ODEF_MF_FN void ex_put(double* __restrict__ ex, int u, const Geo& G, const d4& t) {
-    double* dst = ex + u * TSZ + G.g * TR + G.j;
+    const int base = u * TSZ + G.g * TR + G.j;
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
-      if (G.ok[v]) dst[4 * v * TR] = t[v];
+    for (int v = 0; v < 4; ++v) ex[G.ok[v] ? base + 4 * v * TR : W::DUMMY + G.lane] = t[v];  // no exec masking
   }
 
   // (C_P)' = Hs' (.) over the tiles of the first two derivative blocks of every tile column, panel OUT[row][a]:
   //   block 0 (tiles Q = 0, 1):  H0-part, 8 MFMAs per tile;  block 1 (tiles 2, 3):  h1 I, one FMA per element
-  ODEF_MF_FN void hproject(const d4 (&T)[NT], const Slots& S, const Geo& G, const double* __restrict__ hs0,
+  ODEF_MF_FN void hproject(const d4 (&T)[NS], const Slots& S, const Geo& G0, const double* __restrict__ hs0,
                            const double* __restrict__ tl, double h1, double* __restrict__ out) {
+    const Geo G = fresh(G0);
     d4 acc0 = mf::zero4(), acc1 = mf::zero4();
-    static_for<0, NT>([&](auto sc_) {
+    static_for<0, NS>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
       const int Q = S.tq[s], P = S.tp[s];
       if (Q >= 0) {
@@ -155,7 +221,7 @@ struct MfmaFilter {
         } else if (Q == 3) {
           acc1 += h1 * T[s];
         }
-        if (Q == P) {  // last tile of the column: the sources ABOVE the diagonal come transposed from the LDS copies
+        if (Q == (P < 3 ? P : 3)) {  // last head tile of the column: the sources ABOVE the diagonal come transposed from the LDS copies
 #pragma unroll
           for (int Qc = 1; Qc <= 3; ++Qc) {
             if (Qc > P) {
@@ -177,11 +243,14 @@ struct MfmaFilter {
               }
             }
           }
-          double* o = out + (16 * P + G.j) * LDP + G.g;
+          // the panel is indexed by the PLAIN measurement index a (28 real columns + 4 zero ones: 7 k-steps in the rank
+          // updates instead of 8): row i of accumulator ta is a = 14 ta + i for i < 14; its two zero rows go to 28 + 2 ta + (i - 14)
+          double* o = out + (16 * P + G.j) * LDP;
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            o[4 * v] = acc0[v];
-            o[16 + 4 * v] = acc1[v];
+            const int i = 4 * v + G.g;
+            o[i < TR ? i : 2 * TR + (i - TR)] = acc0[v];
+            o[i < TR ? TR + i : 2 * TR + 2 + (i - TR)] = acc1[v];
           }
           acc0 = mf::zero4();
           acc1 = mf::zero4();
@@ -192,8 +261,9 @@ struct MfmaFilter {
 
   // the ten tiles of the first four tile columns, as full 16 x 16 row-major copies: the six above the diagonal (read
   // back transposed by hproject) and the four diagonal ones (read back through their upper triangle by diag_resym)
-  ODEF_MF_FN void tl_put(const d4 (&T)[NT], const Slots& S, const Geo& G, double* __restrict__ tl, bool with_diag) {
-    static_for<0, NT>([&](auto sc_) {
+  ODEF_MF_FN void tl_put(const d4 (&T)[NS], const Slots& S, const Geo& G0, double* __restrict__ tl, bool with_diag) {
+    const Geo G = fresh(G0);
+    static_for<0, NS>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
       const int Q = S.tq[s], P = S.tp[s];
       if (Q >= 0 && P <= 3 && (Q < P || with_diag)) {
@@ -205,8 +275,9 @@ struct MfmaFilter {
   }
   // A diagonal tile must be EXACTLY symmetric where it enters a product as a whole (H (.) tile): its antisymmetric part
   // is not damped by the update but multiplied by (I + K H), step after step (numpy model in DESIGN.md section 3.9).
-  ODEF_MF_FN void diag_resym(d4 (&T)[NT], const Slots& S, const Geo& G, const double* __restrict__ tl) {
-    static_for<0, NT>([&](auto sc_) {
+  ODEF_MF_FN void diag_resym(d4 (&T)[NS], const Slots& S, const Geo& G0, const double* __restrict__ tl) {
+    const Geo G = fresh(G0);
+    static_for<0, NS>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
       const int Q = S.tq[s], P = S.tp[s];
       if (Q >= 0 && Q == P && P <= 3) {
@@ -220,40 +291,43 @@ struct MfmaFilter {
     });
   }
 
-  // T[s] -= A_panel[tile row Q] B_panel[tile row P]'  (rank-32 update of every tile; a = 28 real + 4 zero columns)
-  ODEF_MF_FN void rank_update(d4 (&T)[NT], const Slots& S, const Geo& G, const double* __restrict__ ap,
+  static constexpr int KS = (d + 3) / 4;  // k-steps of a product over the measurement index
+  // T[s] -= A_panel[tile row Q] B_panel[tile row P]'  (rank-d update of every tile)
+  ODEF_MF_FN void rank_update(d4 (&T)[NS], const Slots& S, const Geo& G0, const double* __restrict__ ap,
                               const double* __restrict__ bp) {
-    double bf[8];
-    static_for<0, NT>([&](auto sc_) {
+    const Geo G = fresh(G0);
+    double bf[KS];
+    static_for<0, NS>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
       const int Q = S.tq[s], P = S.tp[s];
       if (Q >= 0) {
-        if (Q == 0) {  // first tile of a column: its B fragments (negated: the product is subtracted)
+        bool reload = true;
+        if constexpr (s > 0) reload = S.tp[s - 1] != P;
+        if (reload) {  // first tile of a run of one column: its B fragments (negated: the product is subtracted)
           const double* b = bp + (16 * P + G.j) * LDP + G.g;
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks) bf[ks] = -b[4 * ks];
+          for (int ks = 0; ks < KS; ++ks) bf[ks] = -b[4 * ks];
         }
         const double* a = ap + (16 * Q + G.j) * LDP + G.g;
         d4 acc = T[s];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) acc = mf::mfma(a[4 * ks], bf[ks], acc);
+        for (int ks = 0; ks < KS; ++ks) acc = mf::mfma(a[4 * ks], bf[ks], acc);
         T[s] = acc;
       }
     });
   }
 
-  // Cholesky of the 32 x 32 (28 real) innovation covariance in two 16 x 16 blocks and W = L^-1 into wl[32][LDP]; one
-  // wavefront.  sb11 / sb22: the diagonal blocks (+ 16 reciprocal pivots behind each), sb21: the block below.
-  ODEF_MF_FN void factor_s(double* __restrict__ sb11, double* __restrict__ sb22, double* __restrict__ sb21,
-                           double* __restrict__ lw, double* __restrict__ l21, double* __restrict__ wl, const Geo& G) {
-    // W_S starts as zero (upper right block and everything a failed pivot leaves untouched)
-    for (int e = mf::lane64(); e < 32 * LDP; e += 64) wl[e] = 0.0;
-    tv::lds_sync();
-    mf::diag_block_factor(sb11, lw, wl, LDP);
+  // Cholesky of a 32 x 32 (28 real, plain index: 16 + 12) SPD matrix in two 16 x 16 blocks, by one wavefront:
+  //   sb11 / sb22: the diagonal blocks (+ 16 reciprocal pivots behind each), sb21: the block below them (row-major [16][16])
+  //   out: w11 / w22 = inverses of the two diagonal factors (pitch ldw), l21 = L21 [16][16]
+  // (in two halves, so that the helper can spread the factorisation of H Q H' over two barrier intervals)
+  ODEF_MF_FN void chol2_a(double* __restrict__ sb11, double* __restrict__ sb22, const double* __restrict__ sb21,
+                          double* __restrict__ l21, double* __restrict__ w11, int ldw, const Geo& G) {
+    mf::diag_block_factor(sb11, nullptr, w11, ldw);
     // L21 = S21 W11'
     d4 acc = mf::zero4();
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) acc = mf::mfma(sb21[G.j * 16 + 4 * ks + G.g], wl[G.j * LDP + 4 * ks + G.g], acc);
+    for (int ks = 0; ks < 4; ++ks) acc = mf::mfma(sb21[G.j * 16 + 4 * ks + G.g], w11[G.j * ldw + 4 * ks + G.g], acc);
 #pragma unroll
     for (int v = 0; v < 4; ++v) l21[(4 * v + G.g) * 16 + G.j] = acc[v];
     tv::lds_sync();
@@ -269,9 +343,16 @@ struct MfmaFilter {
 #pragma unroll
     for (int v = 0; v < 4; ++v) sb22[(4 * v + G.g) * 16 + G.j] = acc[v];
     tv::lds_sync();
-    mf::diag_block_factor(sb22, lw, wl + 16 * LDP + 16, LDP);
+  }
+  ODEF_MF_FN void chol2_b(double* __restrict__ sb22, double* __restrict__ w22, int ldw) { mf::diag_block_factor(sb22, nullptr, w22, ldw); }
+  // W = L^-1 of the innovation covariance into wl[32][LDP] (lower triangular)
+  ODEF_MF_FN void factor_s(double* __restrict__ sb11, double* __restrict__ sb22, double* __restrict__ sb21,
+                           double* __restrict__ l21, double* __restrict__ wl, const Geo& G) {
+    for (int e = G.lane; e < 16 * 16; e += 64) wl[(e >> 4) * LDP + 16 + (e & 15)] = 0.0;  // the block above the diagonal
+    chol2_a(sb11, sb22, sb21, l21, wl, LDP, G);
+    chol2_b(sb22, wl + 16 * LDP + 16, LDP);
     // W21 = -W22 (L21 W11)
-    acc = mf::zero4();
+    d4 acc = mf::zero4();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) acc = mf::mfma(l21[G.j * 16 + 4 * ks + G.g], wl[(4 * ks + G.g) * LDP + G.j], acc);
     d4 w21 = mf::zero4();
@@ -281,10 +362,20 @@ struct MfmaFilter {
     for (int v = 0; v < 4; ++v) wl[(16 + 4 * v + G.g) * LDP + G.j] = w21[v];
     tv::lds_sync();
   }
+  // sum over the wavefront
+  ODEF_MF_FN double wave_sum(double x) {
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) x += __shfl_xor(x, msk, 64);
+    return x;
+  }
 
   // ---------------------------------------------------------------------------------------------------------- step
+  // Compiled twice from the same source (as filter_tiles.h): HELPER = the wavefront without tiles.  Both instantiations
+  // execute the same number of barriers; neither carries the other's registers.
+  template <bool HELPER>
   ODEF_MF_FN void step(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab, int fixed_diffusion,
-                       int success_iter, double* __restrict__ sm, d4 (&T)[NT], const Slots& S, const Geo& G, int tid, int wave) {
+                       int success_iter, double* __restrict__ sm, d4 (&T)[NS], const Slots& S, const Geo& G0, int tid, int wave) {
+    Geo G = fresh(G0);
     double* ex = sm + W::EX;
     double* vp = sm + W::VP;
     double* kp = sm + W::KP;
@@ -298,20 +389,29 @@ struct MfmaFilter {
     double* mt = sm + W::MT;
     double* mp = sm + W::MP;
     double* z = sm + W::Z;
-    double* zp = sm + W::ZP;
     double* y = sm + W::YV;
     double* up = sm + W::UP;
     double* du = sm + W::DU;
     double* sc = sm + W::SC;
     const double pi0 = tab[kTabPIJ + 0], pi1 = tab[kTabPIJ + 1], h1 = pi1;
 
+    ODEF_MF_STAMP(0)
     // x~ = P x (src/perform_step.jl:36-38): the covariance tiles go to the exchange as they are, the scaling is folded
     // into the coefficients of the congruence
     if (tid < D) mt[tid] = tab[kTabPJ + tid / d] * m[tid];
-    static_for<0, NT>([&](auto sc_) {
-      constexpr int s = decltype(sc_)::value;
-      if (S.tq[s] >= 0) ex_put(ex, uidx(S.tq[s], S.tp[s]), G, T[s]);
-    });
+    if constexpr (HELPER) {  // coefficient tables of the congruence (read as LDS broadcasts: no scalar loads inside the tile loops)
+      for (int e = G.lane; e < NB * NB * NB; e += 64) {
+        const int a = e / (NB * NB), b = (e / NB) % NB, k = e % NB;
+        sm[W::CF1 + e] = pc.At[a][k] * (tab[kTabPJ + k] * tab[kTabPJ + b]);
+      }
+      for (int e = G.lane; e < NB * NB; e += 64) sm[W::CF2 + e] = pc.At[e / NB][e % NB];
+    }
+    if constexpr (!HELPER) {
+      static_for<0, NS>([&](auto sc_) {
+        constexpr int s = decltype(sc_)::value;
+        if (S.tq[s] >= 0) ex_put(ex, uidx(S.tq[s], S.tp[s]), G, T[s]);
+      });
+    }
     __syncthreads();
     // m^- = A m~ , u_pred  (src/filtering.jl:22-25, src/perform_step.jl:43)
     if (tid < D) {
@@ -322,6 +422,7 @@ struct MfmaFilter {
       if (tid < d) up[tid] = pi0 * s;
     }
     __syncthreads();
+    ODEF_MF_STAMP(1)
     // measure! (src/perform_step.jl:95-132)
     if constexpr (HasTeamEval<RHS>::value) {
       static_assert(RHS::team_scratch <= d * W::LDd, "pair buffer must fit the W area");
@@ -339,11 +440,8 @@ struct MfmaFilter {
       }
       __syncthreads();
     }
-    if (tid < d) {
-      const double zz = pi1 * mp[d + tid] - du[tid];
-      z[tid] = zz;
-      zp[pad_d(tid)] = zz;
-    }
+    ODEF_MF_STAMP(2)
+    if (tid < d) z[tid] = pi1 * mp[d + tid] - du[tid];
     for (int e = tid; e < d * d; e += NTHR) {  // H0 = -J pi0 ; M0 = H0 QL00 + I h1 QL10 (src/diffusions.jl:78)
       const int r = e / d, a = e % d;
       double h0 = 0.0;
@@ -361,7 +459,7 @@ struct MfmaFilter {
         WM[r * W::LDd + s_] = acc;
         if (r == s_) sm[W::WD + r] = acc;  // diag(H Q H') for the error estimate (src/perform_step.jl:148-158)
       }
-      for (int e = tid; e < 32 * LDP; e += NTHR) {  // Hs0[k][a] = H0[a][k] in padded indices, zero elsewhere
+      for (int e = tid; e < 32 * LDP; e += NTHR) {  // Hs0[k][a] = H0[a][k] in padded (tile) indices, zero elsewhere
         const int kp_ = e / LDP, ap_ = e % LDP;
         double v = 0.0;
         if (ap_ < 32 && (kp_ & 15) < TR && (ap_ & 15) < TR) v = H0[((ap_ >> 4) * TR + (ap_ & 15)) * d + (kp_ >> 4) * TR + (kp_ & 15)];
@@ -369,107 +467,153 @@ struct MfmaFilter {
       }
     }
     __syncthreads();
-    // sigma^2 = z' W^-1 z / d (src/diffusions.jl:72-80) on the least loaded wavefront, beside the first stage of the
-    // congruence of the others
-    if (!fixed_diffusion && wave == kHelper) {
-      const double acc = wv::chol_quadform<d>(wv::lds(WM), W::LDd, wv::lds(z));
-      wv::store_uniform(wv::lds(sc + 0), acc / d);
-      wv::store_uniform(wv::lds(sc + 4), acc / d);
-    }
-    // predict_cov! (src/filtering.jl:33-41) in two stages through the tile exchange, whole tiles onto whole tiles:
-    //   Z(Q, P) = sum_{k >= Q/2} At[Q/2][k] pj[k] pj[P/2] S(2k + Q%2, P)     sources in the own tile COLUMN; those below the
-    //                                                                        diagonal are read transposed (S symmetric)
-    //   S^-(Q, P) = sum_{k >= P/2} At[P/2][k] Z(Q, 2k + P%2) + sigma2 Qt     sources in the own tile ROW, all of them kept
-    static_for<0, NT>([&](auto sc_) {
-      constexpr int s = decltype(sc_)::value;
-      const int Q = S.tq[s], P = S.tp[s];
-      if (Q >= 0) {
-        const int a = Q >> 1, hq = Q & 1, b = P >> 1;
-        const double pjb = tab[kTabPJ + b];
-        d4 acc = mf::zero4();
-        for (int k = a; k < NB; ++k) {
-          const int Qs = 2 * k + hq;
-          const double coef = pc.At[a][k] * (tab[kTabPJ + k] * pjb);
-          if (Qs < P) {
-            const double* src = ex + uidx(Qs, P) * TSZ + G.g * TR + G.j;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[v] += coef * src[4 * v * TR];
-          } else if (Qs == P) {  // a diagonal tile is its upper triangle (the rank updates leave rounding-level asymmetry)
-            const double* src = ex + uidx(Qs, P) * TSZ;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[v] += coef * src[G.sym[v]];
-          } else {
-            const double* src = ex + uidx(P, Qs) * TSZ + G.j * TR + G.g;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[v] += coef * src[4 * v];
-          }
+    ODEF_MF_STAMP(3)
+    G = fresh(G0);
+    if constexpr (HELPER) {
+      // sigma^2 = z' W^-1 z / d (src/diffusions.jl:72-80): blocked Cholesky of W = H Q H' beside the congruence of the
+      // others -- first half here, second half beside stage 2
+      if (!fixed_diffusion) {
+        double* c11 = sm + W::CW11;
+        double* c22 = sm + W::CW22;
+        double* c21 = sm + W::CW21;
+        for (int e = G.lane; e < 256; e += 64) {
+          const int r = e >> 4, c = e & 15;
+          c11[e] = WM[r * W::LDd + c];
+          c21[e] = (16 + r < d) ? WM[(16 + r) * W::LDd + c] : 0.0;
+          c22[e] = (16 + r < d && 16 + c < d) ? WM[(16 + r) * W::LDd + 16 + c] : 0.0;
         }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) T[s][v] = G.ok[v] ? acc[v] : 0.0;
+        tv::lds_sync();
+        chol2_a(c11, c22, c21, sm + W::CWL, sm + W::CWW1, 16, G);
       }
-    });
-    __syncthreads();
-    static_for<0, NT>([&](auto sc_) {
-      constexpr int s = decltype(sc_)::value;
-      if (S.tq[s] >= 0) ex_put(ex, uidx(S.tq[s], S.tp[s]), G, T[s]);
-    });
-    __syncthreads();
-    {
-      const double sigma2_pred = fixed_diffusion ? 1.0 : sc[0];
-      static_for<0, NT>([&](auto sc_) {
+    } else {
+      // predict_cov! (src/filtering.jl:33-41) in two stages through the tile exchange, whole tiles onto whole tiles:
+      //   Z(Q, P) = sum_{k >= Q/2} At[Q/2][k] pj[k] pj[P/2] S(2k + Q%2, P)     sources in the own tile COLUMN; those below the
+      //                                                                        diagonal are read transposed (S symmetric)
+      //   S^-(Q, P) = sum_{k >= P/2} At[P/2][k] Z(Q, 2k + P%2)  ( + sigma2 Qt later )   sources in the own tile ROW, all kept
+      static_for<0, NS>([&](auto sc_) {
         constexpr int s = decltype(sc_)::value;
         const int Q = S.tq[s], P = S.tp[s];
         if (Q >= 0) {
-          const int a = Q >> 1, hq = Q & 1, b = P >> 1, hp = P & 1;
+          const int a = Q >> 1, hq = Q & 1, b = P >> 1;
+          const double* cf = sm + W::CF1 + (a * NB + b) * NB;
           d4 acc = mf::zero4();
+          for (int k = a; k < NB; ++k) {
+            const int Qs = 2 * k + hq;
+            const double coef = cf[k];
+            if (Qs < P) {
+              const double* src = ex + uidx(Qs, P) * TSZ + G.g * TR + G.j;
+#pragma unroll
+              for (int v = 0; v < 4; ++v) acc[v] += coef * src[4 * v * TR];
+            } else if (Qs == P) {  // a diagonal tile is its upper triangle (the rank updates leave rounding-level asymmetry)
+              const double* src = ex + uidx(Qs, P) * TSZ;
+#pragma unroll
+              for (int v = 0; v < 4; ++v) acc[v] += coef * src[G.sym[v]];
+            } else {
+              const double* src = ex + uidx(P, Qs) * TSZ + G.j * TR + G.g;
+#pragma unroll
+              for (int v = 0; v < 4; ++v) acc[v] += coef * src[4 * v];
+            }
+          }
+#pragma unroll
+          for (int v = 0; v < 4; ++v) T[s][v] = G.ok[v] ? acc[v] : 0.0;
+        }
+      });
+    }
+    __syncthreads();
+    ODEF_MF_STAMP(4)
+    G = fresh(G0);
+    if constexpr (!HELPER) {
+      static_for<0, NS>([&](auto sc_) {
+        constexpr int s = decltype(sc_)::value;
+        if (S.tq[s] >= 0) ex_put(ex, uidx(S.tq[s], S.tp[s]), G, T[s]);
+      });
+    }
+    __syncthreads();
+    ODEF_MF_STAMP(5)
+    G = fresh(G0);
+    if constexpr (HELPER) {
+      if (!fixed_diffusion) {
+        double* w1 = sm + W::CWW1;
+        double* w2 = sm + W::CWW2;
+        chol2_b(sm + W::CW22, w2, 16);
+        // y = L^-1 z: y1 = W11 z1, y2 = W22 (z2 - L21 y1); lanes 0..15 hold y1, lanes 16..31 hold y2
+        const int l = G.lane, r = l & 15;
+        double y1 = 0.0;
+        for (int b = 0; b <= r; ++b) y1 += w1[r * 16 + b] * z[b];
+        double t2 = z[16 + r];  // zero beyond d
+        for (int b = 0; b < 16; ++b) t2 -= sm[W::CWL + r * 16 + b] * __shfl(y1, b, 64);
+        double y2 = 0.0;
+        for (int b = 0; b <= r; ++b) y2 += w2[r * 16 + b] * __shfl(t2, b, 64);
+        const double acc = wave_sum(l < 16 ? y1 * y1 : l < 32 ? y2 * y2 : 0.0);
+        if (l == 0) {
+          sc[0] = acc / d;
+          sc[4] = acc / d;
+        }
+      }
+    } else {
+      static_for<0, NS>([&](auto sc_) {
+        constexpr int s = decltype(sc_)::value;
+        const int Q = S.tq[s], P = S.tp[s];
+        if (Q >= 0) {
+          const int b = P >> 1, hp = P & 1;
+          d4 acc = mf::zero4();
+          const double* cf = sm + W::CF2 + b * NB;
           for (int k = b; k < NB; ++k) {
-            const double coef = pc.At[b][k];
+            const double coef = cf[k];
             const double* src = ex + uidx(Q, 2 * k + hp) * TSZ + G.g * TR + G.j;
 #pragma unroll
             for (int v = 0; v < 4; ++v) acc[v] += coef * src[4 * v * TR];
           }
-          const double sq = (hq == hp) ? sigma2_pred * pc.Qt[a][b] : 0.0;
 #pragma unroll
-          for (int v = 0; v < 4; ++v) T[s][v] = G.ok[v] ? acc[v] + ((4 * v + G.g == G.j) ? sq : 0.0) : 0.0;
+          for (int v = 0; v < 4; ++v) T[s][v] = G.ok[v] ? acc[v] : 0.0;
         }
       });
     }
     __syncthreads();  // the exchange is dead: region R0 now holds the panels
-    tl_put(T, S, G, tl, true);
+    ODEF_MF_STAMP(6)
+    if constexpr (!HELPER) tl_put(T, S, G0, tl, true);
     __syncthreads();
-    diag_resym(T, S, G, tl);
-    hproject(T, S, G, hs0, tl, h1, vp);  // C = S^- H' into the V panel
-    __syncthreads();
-    // Sm = H C (d x d): one 16 x 16 block per wavefront (the block above the diagonal is not needed)
-    if (wave < 4 && wave != 1) {
-      const int ta = wave >> 1, tb = wave & 1;
-      d4 acc = mf::zero4();
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
-        acc = mf::mfma(hs0[(4 * ks + G.g) * LDP + G.j + 16 * ta], vp[(4 * ks + G.g) * LDP + G.j + 16 * tb], acc);
-      double* dst = sm + (wave == 0 ? W::SB11 : wave == 3 ? W::SB22 : W::SB21);
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-        dst[(4 * v + G.g) * 16 + G.j] = acc[v] + h1 * vp[(32 + 16 * ta + 4 * v + G.g) * LDP + 16 * tb + G.j];
+    ODEF_MF_STAMP(7)
+    if constexpr (!HELPER) {
+      diag_resym(T, S, G0, tl);
+      hproject(T, S, G0, hs0, tl, h1, vp);  // C0 = (A S A') H' into the V panel
     }
-    __syncthreads();
-    // Cholesky of Sm, W = L^-1, y = W z, z'Sm^-1 z and log det Sm (src/perform_step.jl:66): one wavefront
-    if (wave == kHelper) {
-      factor_s(sm + W::SB11, sm + W::SB22, sm + W::SB21, sm + W::LW, sm + W::L21, wl, G);
-      const int l = mf::lane64();
+    __syncthreads();  // ... and sigma^2 is there
+    ODEF_MF_STAMP(8)
+    G = fresh(G0);
+    const double sigma2_pred = fixed_diffusion ? 1.0 : sc[0];
+    if constexpr (HELPER) {
+      // Sm = H C = H C0 + sigma2 H Q H' (d x d, plain index): the three blocks of its lower triangle, then its Cholesky,
+      // W = L^-1, y = W z, z'Sm^-1 z and log det Sm (src/perform_step.jl:66)
+      static_for<0, 3>([&](auto bc) {
+        constexpr int blk = decltype(bc)::value;  // 0: (0,0)  1: (1,0)  2: (1,1)
+        constexpr int ta = blk >= 1, tb = blk == 2;
+        const int a_ = 16 * ta + G.j;                                   // A operand: row a of H (plain) = column pad_d(a) of Hs0
+        const int acol = a_ < d ? pad_d(a_) : TR;                       // a zero column of Hs0 for the padding rows
+        d4 acc = mf::zero4();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+          acc = mf::mfma(hs0[(4 * ks + G.g) * LDP + acol], vp[(4 * ks + G.g) * LDP + G.j + 16 * tb], acc);
+        double* dst = sm + (blk == 0 ? W::SB11 : blk == 1 ? W::SB21 : W::SB22);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int a = 16 * ta + 4 * v + G.g, b = 16 * tb + G.j;
+          double x = 0.0;
+          if (a < d && b < d) x = acc[v] + h1 * vp[(32 + pad_d(a)) * LDP + b] + sigma2_pred * WM[a * W::LDd + b];
+          dst[(4 * v + G.g) * 16 + G.j] = x;
+        }
+      });
+      tv::lds_sync();
+      factor_s(sm + W::SB11, sm + W::SB22, sm + W::SB21, sm + W::L21, wl, G);
+      const int l = G.lane;
       double yv = 0.0, lg = 0.0;
       if (l < 32) {
-        for (int b = 0; b <= l; ++b) yv += wl[l * LDP + b] * zp[b];
+        for (int b = 0; b <= l; ++b) yv += wl[l * LDP + b] * z[b];
         const double rp = (l < 16) ? sm[W::SB11 + 256 + l] : sm[W::SB22 + 256 + l - 16];
         lg = (rp > 0.0) ? -log(rp) : 0.0;
         y[l] = yv;
       }
-      double zSz = yv * yv, logacc = lg;
-#pragma unroll
-      for (int msk = 32; msk >= 1; msk >>= 1) {
-        zSz += __shfl_xor(zSz, msk, 64);
-        logacc += __shfl_xor(logacc, msk, 64);
-      }
+      const double zSz = wave_sum(yv * yv), logacc = wave_sum(lg);
       if (l == 0) {
         sc[1] = zSz;
         sc[3] = sc[3] - 0.5 * (zSz + 2.0 * logacc + d * 1.8378770664093453);
@@ -480,13 +624,37 @@ struct MfmaFilter {
           sc[4] = static_diffusion_update<d>(fixed_diffusion, success_iter, prev, dt_);
         }
       }
+    } else {
+      // + sigma2 Q on the tiles (src/filtering.jl:35): Qt[Q/2][P/2] on the diagonal of the tiles with equal halves
+      static_for<0, NS>([&](auto sc_) {
+        constexpr int s = decltype(sc_)::value;
+        const int Q = S.tq[s], P = S.tp[s];
+        if (Q >= 0 && (Q & 1) == (P & 1)) {
+          const double sq = sigma2_pred * pc.Qt[Q >> 1][P >> 1];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) T[s][v] += (G.ok[v] && 4 * v + G.g == G.j) ? sq : 0.0;
+        }
+      });
     }
     __syncthreads();
-    // V = C W' (in place) and K = V W, one tile row of the panels at a time
+    ODEF_MF_STAMP(10)
+    G = fresh(G0);
+    // per tile row R of the panels, one wavefront: C = C0 + sigma2 Q H', then V = C W' (in place) and K = V W
     for (int R = wave; R < NT; R += kMfWaves) {
+      {
+        const int bq = R >> 1, hr = R & 1;
+        const double q0 = sigma2_pred * pc.Qt[bq][0], q1 = sigma2_pred * pc.Qt[bq][1] * h1;
+        for (int e = G.lane; e < TR * d; e += 64) {  // (Q H')[r][a] = Qt[b][0] H0[a][i] + Qt[b][1] h1 [a == i],  r = (b, i)
+          const int ii = e / d, a = e % d, i = TR * hr + ii;
+          double x = q0 * hs0[pad_d(i) * LDP + pad_d(a)];
+          if (a == i) x += q1;
+          vp[(16 * R + ii) * LDP + a] += x;
+        }
+      }
+      tv::lds_sync();
       d4 v0 = mf::zero4(), v1 = mf::zero4();
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         const double a = vp[(16 * R + G.j) * LDP + 4 * ks + G.g];
         v0 = mf::mfma(a, wl[G.j * LDP + 4 * ks + G.g], v0);
         v1 = mf::mfma(a, wl[(16 + G.j) * LDP + 4 * ks + G.g], v1);
@@ -500,7 +668,7 @@ struct MfmaFilter {
       tv::lds_sync();
       d4 k0 = mf::zero4(), k1 = mf::zero4();
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         const double a = vp[(16 * R + G.j) * LDP + 4 * ks + G.g];
         k0 = mf::mfma(a, wl[(4 * ks + G.g) * LDP + G.j], k0);
         k1 = mf::mfma(a, wl[(4 * ks + G.g) * LDP + 16 + G.j], k1);
@@ -512,55 +680,68 @@ struct MfmaFilter {
       }
     }
     __syncthreads();
+    ODEF_MF_STAMP(11)
+    G = fresh(G0);
     // m = m^- - V y (src/filtering.jl:87), un-preconditioned (src/perform_step.jl:75);  T = S^- - V V'
     if (tid < D) {
       const int prow = 32 * (tid / d) + pad_d(tid % d);
       double s = mp[tid];
-#pragma unroll 8
-      for (int a = 0; a < 32; ++a) s -= vp[prow * LDP + a] * y[a];
+#pragma unroll 7
+      for (int a = 0; a < d; ++a) s -= vp[prow * LDP + a] * y[a];
       m[tid] = tab[kTabPIJ + tid / d] * s;
     }
-    rank_update(T, S, G, vp, vp);  // bitwise symmetric on the diagonal tiles (same products, same order)
+    if constexpr (!HELPER) rank_update(T, S, G0, vp, vp);  // bitwise symmetric on the diagonal tiles (same products, same order)
     __syncthreads();
-    tl_put(T, S, G, tl, false);
+    ODEF_MF_STAMP(12)
+    if constexpr (!HELPER) tl_put(T, S, G0, tl, false);
     __syncthreads();
-    hproject(T, S, G, hs0, tl, h1, vp);  // E = T H' over the V panel
+    ODEF_MF_STAMP(13)
+    if constexpr (!HELPER) hproject(T, S, G0, hs0, tl, h1, vp);  // E = T H' over the V panel
     __syncthreads();
-    rank_update(T, S, G, vp, kp);  // S = T - E K'
-    static_for<0, NT>([&](auto sc_) {  // un-precondition (src/perform_step.jl:73-75)
-      constexpr int s = decltype(sc_)::value;
-      if (S.tq[s] >= 0) T[s] *= tab[kTabPIPI + (S.tq[s] >> 1) * MAXNB + (S.tp[s] >> 1)];
-    });
+    ODEF_MF_STAMP(14)
+    if constexpr (!HELPER) {
+      rank_update(T, S, G0, vp, kp);  // S = T - E K'
+      static_for<0, NS>([&](auto sc_) {  // un-precondition (src/perform_step.jl:73-75)
+        constexpr int s = decltype(sc_)::value;
+        if (S.tq[s] >= 0) T[s] *= tab[kTabPIPI + (S.tq[s] >> 1) * MAXNB + (S.tp[s] >> 1)];
+      });
+    }
     __syncthreads();
+    ODEF_MF_STAMP(15)
   }
 
+  template <bool HELPER>
   ODEF_MF_FN void save_record(const FilterParams& P, long i, long slot, double diffusion, const double* __restrict__ sm,
-                              const d4 (&T)[NT], const Slots& S, const Geo& G, int tid) {
+                              const d4 (&T)[NS], const Slots& S, const Geo& G, int tid) {
     const double* m = sm + W::MV;
     const size_t N = (size_t)P.N;
     if (tid < D) P.mean[((size_t)slot * D + tid) * N + i] = m[tid];
-    static_for<0, NT>([&](auto sc_) {
-      constexpr int s = decltype(sc_)::value;
-      const int Q = S.tq[s], Pc = S.tp[s];
-      if (Q >= 0) {
+    if constexpr (!HELPER) {
+      static_for<0, NS>([&](auto sc_) {
+        constexpr int s = decltype(sc_)::value;
+        const int Q = S.tq[s], Pc = S.tp[s];
+        if (Q >= 0) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int a = Q * TR + 4 * v + G.g, b = Pc * TR + G.j;  // row <= column in the kept triangle
-          if (G.ok[v] && a <= b) P.cov[((size_t)slot * TRI + tri(b, a)) * N + i] = T[s][v];
+          for (int v = 0; v < 4; ++v) {
+            const int a = Q * TR + 4 * v + G.g, b = Pc * TR + G.j;  // row <= column in the kept triangle
+            if (G.ok[v] && a <= b) P.cov[((size_t)slot * TRI + tri(b, a)) * N + i] = T[s][v];
+          }
         }
-      }
-    });
+      });
+    }
     if (tid == 0) P.diff[(size_t)slot * N + i] = diffusion;
   }
 
   // whole fixed-step solve of trajectory i
+  template <bool HELPER>
   ODEF_MF_FN void run(const FilterParams& P, long i, int tid, double* __restrict__ sm) {
     double* m = sm + W::MV;
     double* sc = sm + W::SC;
     const size_t N = (size_t)P.N;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     Geo G;
-    G.g = (tid & 63) >> 4;
+    G.lane = tid & 63;
+    G.g = G.lane >> 4;
     G.j = tid & 15;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -569,10 +750,10 @@ struct MfmaFilter {
       G.sym[v] = (i < G.j ? i : G.j) * TR + (i < G.j ? G.j : i);
     }
     Slots S;
-    static_for<0, NT>([&](auto sc_) {
+    static_for<0, NS>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
       int qq = -1, pp = -1;
-      static_for<0, kMfWaves>([&](auto wc) {
+      static_for<0, kMfTileWaves>([&](auto wc) {
         constexpr int w = decltype(wc)::value;
         constexpr int cq = make_mf_own<NT>().Q[w][s], cp = make_mf_own<NT>().P[w][s];
         if (wave == w) {
@@ -583,13 +764,13 @@ struct MfmaFilter {
       S.tq[s] = qq;
       S.tp[s] = pp;
     });
-    d4 T[NT];
+    d4 T[NS];
 #pragma unroll
-    for (int s = 0; s < NT; ++s) T[s] = mf::zero4();
+    for (int s = 0; s < NS; ++s) T[s] = mf::zero4();
     __attribute__((unused)) double pl_local[RHS::np > 0 ? RHS::np : 1];
     const double* pl = pl_local;
     for (int k = 0; k < RHS::np; ++k) pl_local[k] = P.p_shared ? P.p[k] : P.p[(size_t)k * N + i];
-    if (tid == 0) {  // Taylor-mode initial mean (src/state_initialization.jl), zero covariance
+    if (!HELPER && tid == 0) {  // Taylor-mode initial mean (src/state_initialization.jl), zero covariance
       double u0[d], m0[D];
       for (int a = 0; a < d; ++a) u0[a] = P.u0[(size_t)a * N + i];
       taylor_init<RHS, q>(u0, pl, m0);
@@ -597,15 +778,15 @@ struct MfmaFilter {
       for (int k = 0; k < 8; ++k) sc[k] = 0.0;
       for (int a = 0; a < d; ++a) sm[W::UC + a] = u0[a];
     }
-    for (int e = tid; e < 32; e += NTHR) sm[W::ZP + e] = 0.0;
+    for (int e = tid; e < 32; e += NTHR) sm[W::Z + e] = 0.0;  // the entries behind z[d-1] stay zero
     __syncthreads();
-    if (P.everystep) save_record(P, i, 0, 0.0, sm, T, S, G, tid);
+    if (P.everystep) save_record<HELPER>(P, i, 0, 0.0, sm, T, S, G, tid);
     for (long n = 0; n < P.nsteps; ++n) {
       const double* tab = P.ptab + (size_t)uniform_load(P.tab_idx + n) * kTabStride;
-      step(P.pc, pl, tab, P.fixed_diffusion, (int)n, sm, T, S, G, tid, wave);
-      if (P.everystep) save_record(P, i, n + 1, sc[4], sm, T, S, G, tid);
+      step<HELPER>(P.pc, pl, tab, P.fixed_diffusion, (int)n, sm, T, S, G, tid, wave);
+      if (P.everystep) save_record<HELPER>(P, i, n + 1, sc[4], sm, T, S, G, tid);
     }
-    if (!P.everystep) save_record(P, i, 0, sc[4], sm, T, S, G, tid);
+    if (!P.everystep) save_record<HELPER>(P, i, 0, sc[4], sm, T, S, G, tid);
     if (tid == 0) {
       P.loglik[i] = sc[3];
       P.naccept[i] = (int)P.nsteps;
@@ -625,7 +806,10 @@ template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kMfBlock) void ek_filter_mfma_kernel(const FilterParams P) {
   using MF = MfmaFilter<RHS, q, EK1>;
   __shared__ double sm[MF::W::size];
-  MF::run(P, (long)blockIdx.x, (int)threadIdx.x, sm);
+  if (threadIdx.x >= 64 * kMfHelper)  // the helper wavefront: same barriers, its own code path and register allocation
+    MF::template run<true>(P, (long)blockIdx.x, (int)threadIdx.x, sm);
+  else
+    MF::template run<false>(P, (long)blockIdx.x, (int)threadIdx.x, sm);
 }
 
 }  // namespace odef
