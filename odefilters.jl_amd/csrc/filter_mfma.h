@@ -1,5 +1,5 @@
 // EK0/EK1 fixed-step filter for large state dimension (Pleiades: d = 28, D = 168) on the FP64 matrix cores: one
-// 512-thread workgroup per trajectory, the covariance DISTRIBUTED IN REGISTERS as 16 x 16 accumulator tiles of
+// 576-thread workgroup per trajectory, the covariance DISTRIBUTED IN REGISTERS as 16 x 16 accumulator tiles of
 // v_mfma_f64_16x16x4_f64 for the whole solve, LDS (<= 160 KB) as exchange medium and operand store.
 //
 // Formulation (src/perform_step.jl:27-93, src/filtering.jl:33-48,79-91): the same Gaussian conditioning the reference
@@ -14,20 +14,26 @@
 // second stage removes exactly that residual.  In float64 this recursion stays as close to the extended-precision
 // evaluation of the reference algorithm as the reference's own square-root arithmetic.
 // Every D-sized operation is a rank-d product -- 2 d D^2 flops each, on the matrix pipe -- and there is no D-sized
-// factorisation, no Householder QR and no per-pivot synchronisation of the workgroup: the step has 16 barriers instead
+// factorisation, no Householder QR and no per-pivot synchronisation of the workgroup: the step has 11 barriers instead
 // of ~45 (filter_tiles.h, which stays in the library: adaptive solves, ODEF_PLEIADES_FILTER=tiles).
 //
 // Tiles.  Each derivative block (d = 28 rows) is split into two tiles of 14 real rows + 2 zero rows, so that the
 // Kronecker congruence maps whole tiles onto whole tiles (tile 2 b + h <-> rows 14 h .. 14 h + 13 of block b) and
-// DP = 32 (q + 1) = 192 at order 5.  Only tiles (Q, P) with Q <= P are kept (78 of them): tile column P belongs to ONE
-// wavefront (columns are dealt to 7 wavefronts by decreasing size: 12, 11, 11, 11, 11, 11, 11 tiles), in the accumulator layout
+// DP = 32 (q + 1) = 192 at order 5.  Only tiles (Q, P) with Q <= P are kept (78 of them), 9-10 per wavefront, in the
+// accumulator layout
 //     register v of lane l  <->  element (row 4 v + l / 16, column l % 16).
 // A tile in this layout IS the B operand of a K = 16 product (register v = k-step v), so  H (.) tile  needs no data
 // movement; products that need the tile as the A operand (the six tiles above the diagonal of the first two derivative
 // blocks) go through a small LDS copy.  The rank-d updates read their D x d operand panels (V, K, E) from LDS.
-// The eighth wavefront owns no tile: it runs the two d x d factorisations (H Q H' for sigma^2 -- beside the congruence
-// of the others: sigma^2 Q is added to the tiles and sigma^2 Q H' to the panel only after C = (A S A') H' is there -- and
-// Sm, which everybody waits for).
+//
+// Code.  The tile code is instantiated once PER TILE WAVEFRONT (template parameter WAVE): which tiles a wavefront owns
+// is then a compile-time fact, every LDS address is "lane part + immediate", the source lists of the congruence are
+// exact, and a wavefront executes ~2 000 instructions per step instead of ~11 000 of a generic, run-time-indexed
+// version (whose 159 KB also overflowed the 64 KB instruction cache: the helper ran at ~80 cycles per instruction).
+// The ninth wavefront (the helper) owns no tile: it runs the two d x d factorisations -- H Q H' for sigma^2 beside the
+// congruence of the others (sigma^2 Q is added to the tiles and sigma^2 Q H' to the panel only after C0 = (A S A') H' is
+// there), Sm while everybody waits -- and, beside the tail of step n, the whole measurement chain of step n + 1 (mean
+// prediction, f, J, z, H0, M0, H Q H', the padded H0'), which depends on the mean alone.
 #pragma once
 #ifndef ODEF_HOST_EMUL
 #include "ek_lane.h"
@@ -41,12 +47,17 @@ constexpr int kMfWaves = 9;       // wavefronts of the workgroup
 constexpr int kMfTileWaves = 8;   // ... that own tiles; the last one is the helper
 constexpr int kMfHelper = 8;
 constexpr int kMfBlock = 64 * kMfWaves;
+#ifndef ODEF_MF_HELPER_BIAS
+#define ODEF_MF_HELPER_BIAS 0
+#endif
+constexpr int kMfHelperBias = ODEF_MF_HELPER_BIAS;  // tiles fewer for the tile wavefronts that share the helper's SIMD (measured: no gain)
 
 // In-kernel stamps at phase boundaries: ONLY in the diagnostic build of tools/mfma_filter_stamps.hip
-// (-DODEF_MF_STAMPS); the product kernel contains none.
+// (-DODEF_MF_STAMPS); the product kernel contains none.  STAMP: tile thread 0; HSTAMP: the helper's own clock.
 #ifdef ODEF_MF_STAMPS
 __device__ unsigned long long* g_mf_stamp_buf = nullptr;
 __device__ unsigned long long g_mf_stamp_last = 0;
+__device__ unsigned long long g_mf_hstamp_last = 0;
 #define ODEF_MF_STAMP(k)                                                      \
   if (tid == 0 && blockIdx.x == 0 && g_mf_stamp_buf) {                        \
     unsigned long long t_;                                                    \
@@ -54,29 +65,36 @@ __device__ unsigned long long g_mf_stamp_last = 0;
     g_mf_stamp_buf[(k)] += t_ - g_mf_stamp_last;                              \
     g_mf_stamp_last = t_;                                                     \
   }
+#define ODEF_MF_HSTAMP(k)                                                     \
+  if (threadIdx.x == 64 * kMfHelper && blockIdx.x == 0 && g_mf_stamp_buf) {   \
+    unsigned long long t_;                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    g_mf_stamp_buf[16 + (k)] += t_ - g_mf_hstamp_last;                        \
+    g_mf_hstamp_last = t_;                                                    \
+  }
 #else
 #define ODEF_MF_STAMP(k)
+#define ODEF_MF_HSTAMP(k)
 #endif
 
 // Tile ownership.  The "head" of a tile column (its tiles in the first four tile rows: the ones H (.) reads) stays in
 // one wavefront, so that C = S^- H' needs no reduction across wavefronts; every other tile may go anywhere.  Heads are
-// dealt first (largest column first, to the least loaded wavefront), then the remaining tiles column by column, each to
-// the least loaded wavefront (staying with the previous tile's wavefront while that one is below the average load, so
-// that the B fragments of a column are reloaded rarely).  78 tiles over 8 wavefronts: 10, 10, 10, 10, 10, 10, 9, 9.
+// dealt first (largest column first, to the wavefront with most room), then the remaining tiles column by column,
+// staying with a wavefront until it is full (the B fragments of a column are then reloaded rarely).
+// 78 tiles over 8 wavefronts: 9, 9, 10, 10, 10, 10, 10, 10.
 template <int NT>
 struct MfOwnTab {
   static constexpr int ntiles = NT * (NT + 1) / 2;
-  static constexpr int cap = (ntiles + kMfTileWaves - 1) / kMfTileWaves + 3;  // upper bound of a wavefront's load
+  static constexpr int cap = (ntiles + kMfTileWaves - 1) / kMfTileWaves + 4;  // upper bound of a wavefront's load
   int n[kMfTileWaves];
   int Q[kMfTileWaves][cap];
   int P[kMfTileWaves][cap];
-  int maxload;
   bool ok;
 };
 template <int NT>
 constexpr MfOwnTab<NT> make_mf_own() {
   MfOwnTab<NT> t{};
-  constexpr int cap = MfOwnTab<NT>::cap, target = (MfOwnTab<NT>::ntiles + kMfTileWaves - 1) / kMfTileWaves;
+  constexpr int cap = MfOwnTab<NT>::cap, ntiles = MfOwnTab<NT>::ntiles;
   t.ok = true;
   for (int w = 0; w < kMfTileWaves; ++w) {
     t.n[w] = 0;
@@ -85,35 +103,41 @@ constexpr MfOwnTab<NT> make_mf_own() {
       t.P[w][s] = -1;
     }
   }
-  auto least = [&]() {
+  int tgt[kMfTileWaves] = {};
+  {
+    int nb = 0;
+    for (int w = 0; w < kMfTileWaves; ++w) nb += ((w & 3) == (kMfHelper & 3));
+    const int total = ntiles + nb * kMfHelperBias;
+    for (int w = 0; w < kMfTileWaves; ++w) tgt[w] = total / kMfTileWaves - (((w & 3) == (kMfHelper & 3)) ? kMfHelperBias : 0);
+    int rest = ntiles;
+    for (int w = 0; w < kMfTileWaves; ++w) rest -= tgt[w];
+    for (int w = kMfTileWaves - 1; rest > 0; --w, --rest) tgt[w < 0 ? 0 : w] += 1;
+  }
+  auto roomiest = [&]() {
     int w = 0;
     for (int k = 1; k < kMfTileWaves; ++k)
-      if (t.n[k] < t.n[w]) w = k;
+      if (tgt[k] - t.n[k] > tgt[w] - t.n[w]) w = k;
     return w;
   };
-  for (int P = NT - 1; P >= 0; --P) {  // heads
-    const int w = least();
-    for (int Q = 0; Q <= (P < 3 ? P : 3); ++Q) {
-      if (t.n[w] >= cap) { t.ok = false; return t; }
-      t.Q[w][t.n[w]] = Q;
-      t.P[w][t.n[w]] = P;
-      ++t.n[w];
+  auto put = [&](int w, int Q, int P) {
+    if (t.n[w] >= cap) {
+      t.ok = false;
+      return;
     }
+    t.Q[w][t.n[w]] = Q;
+    t.P[w][t.n[w]] = P;
+    ++t.n[w];
+  };
+  for (int P = NT - 1; P >= 0; --P) {  // heads
+    const int w = roomiest();
+    for (int Q = 0; Q <= (P < 3 ? P : 3); ++Q) put(w, Q, P);
   }
-  int prev = -1;
+  int cur = roomiest();
   for (int P = NT - 1; P >= 4; --P)
     for (int Q = 4; Q <= P; ++Q) {
-      int w = least();
-      if (prev >= 0 && t.n[prev] < target) w = prev;
-      if (t.n[w] >= cap) { t.ok = false; return t; }
-      t.Q[w][t.n[w]] = Q;
-      t.P[w][t.n[w]] = P;
-      ++t.n[w];
-      prev = w;
+      if (t.n[cur] >= tgt[cur]) cur = roomiest();
+      put(cur, Q, P);
     }
-  t.maxload = 0;
-  for (int w = 0; w < kMfTileWaves; ++w)
-    if (t.n[w] > t.maxload) t.maxload = t.n[w];
   return t;
 }
 
@@ -122,13 +146,15 @@ struct MfLds {
   static constexpr int D = d * NB, NT = 2 * NB, DP = 16 * NT, ntiles = NT * (NT + 1) / 2;
   static constexpr int TR = d / 2, TSZ = TR * TR;  // real rows per tile; one tile in the exchange
   static constexpr int LDP = 34;                   // pitch of the operand panels (32 + 2: conflict-light fragment reads)
-  // region R0, time-shared: tile exchange of the congruence  |  panels V / E, K + the transposed-role tiles + scratch
+  // region R0, time-shared: tile exchange of the congruence  |  panels V / E, K + the transposed-role tile copies
   static constexpr int EX = 0, EX_size = ntiles * TSZ;
   static constexpr int VP = 0, KP = VP + DP * LDP, TL = KP + DP * LDP;  // TL: 6 tiles above the diagonal + 4 diagonal ones
   static constexpr int R0_need = TL + 10 * 256;
   static constexpr int R0_size = EX_size > R0_need ? EX_size : R0_need;
+  static constexpr int DUMMY = EX_size;  // 64 doubles behind the exchange: where the padding lanes of a tile store go
+  static_assert(R0_size >= EX_size + 64, "room for the dummy stores");
   // region B, time-shared:
-  //   H0 | M0 | WM          raw / scaled Jacobian block, M0, W = H Q H'           (measure ... chol(W))
+  //   H0 | M0 | WM          raw / scaled Jacobian block, M0, W = H Q H'           (measurement chain ... chol(W), Sm)
   //   scratch of chol(W)    over H0 | M0 once W is built: two diagonal blocks (+ pivots), the block below, L21, W11, W22
   //   WL | scratch of Sm    W_S = L^-1 of the innovation covariance [32][LDP], then the blocks of Sm and L21
   static constexpr int LDd = d + 1;
@@ -144,8 +170,6 @@ struct MfLds {
   static constexpr int CF1 = TAB + kTabStride, CF2 = CF1 + NB * NB * NB;  // coefficients of the two congruence stages
   static constexpr int size = CF2 + NB * NB;
   static_assert(d % 2 == 0 && d / 2 <= 16 && d / 2 >= 1, "a derivative block is split into two tiles of d / 2 <= 16 rows");
-  static constexpr int DUMMY = EX_size;  // 64 doubles behind the exchange: where the padding lanes of a tile store go
-  static_assert(R0_size >= EX_size + 64, "room for the dummy stores");
   static_assert(size * 8 <= 160 * 1024, "LDS budget of one workgroup");
 };
 
@@ -155,22 +179,26 @@ struct MfmaFilter {
   using W = MfLds<d, NB>;
   using d4 = mf::d4;
   static constexpr int NT = W::NT, TR = W::TR, TSZ = W::TSZ, LDP = W::LDP, NTHR = kMfBlock;
-  static constexpr int NS = make_mf_own<NT>().maxload;  // tile slots per wavefront
-  static constexpr int kHelper = kMfHelper;
-  static_assert(make_mf_own<NT>().ok, "tile columns do not fit the slot table");
+  static constexpr int KS = (d + 3) / 4;  // k-steps of a product over the measurement index
+  static_assert(make_mf_own<NT>().ok, "tile ownership table overflow");
+  // compile-time tile list of wavefront WAVE (the helper owns none)
+  template <int WAVE>
+  struct Own {
+    static constexpr int w = WAVE < kMfTileWaves ? WAVE : 0;
+    static constexpr int n = WAVE < kMfTileWaves ? make_mf_own<NT>().n[w] : 0;
+    static constexpr int tq(int s) { return make_mf_own<NT>().Q[w][s]; }
+    static constexpr int tp(int s) { return make_mf_own<NT>().P[w][s]; }
+    static constexpr int nreg = n > 0 ? n : 1;
+  };
 
   struct Geo {  // per-lane geometry of the accumulator layout
     int g, j, lane;
     bool ok[4];  // element (4 v + g, j) is a real entry of its tile
     int sym[4];  // offset of element (min, max) of (4 v + g, j) in a compact TR x TR tile: upper-triangle read of a diagonal tile
   };
-  struct Slots {
-    int tq[NS], tp[NS];  // wave-uniform tile coordinates of slot s (-1: unused)
-  };
   // The lane geometry is loop-invariant, and so is every LDS address derived from it: left alone, the compiler hoists a few
-  // hundred of them out of the step loop, runs out of registers and reloads them from scratch inside the phases
-  // (scratch loads share vmcnt with nothing else here, but they sit on the critical path of every phase).  Each phase
-  // therefore starts from a laundered copy -- no instructions, the values just stop being provably invariant.
+  // hundred of them out of the step loop, runs out of registers and reloads them from scratch inside the phases.  Each
+  // phase therefore starts from a laundered copy -- no instructions, the values just stop being provably invariant.
   __device__ __attribute__((always_inline)) static inline Geo fresh(const Geo& G0) {
     Geo G;
     int g = G0.g, j = G0.j, lane = G0.lane;
@@ -189,68 +217,180 @@ struct MfmaFilter {
 
 #define ODEF_MF_FN __device__ __attribute__((always_inline)) static inline
 
-  ODEF_MF_FN int pad_d(int a) { return 16 * (a / TR) + a % TR; }  // measurement / in-block index -> padded
-  ODEF_MF_FN int uidx(int Q, int P) { return P * (P + 1) / 2 + Q; }
+  ODEF_MF_FN constexpr int pad_d(int a) { return 16 * (a / TR) + a % TR; }  // measurement / in-block index -> padded
+  ODEF_MF_FN constexpr int uidx(int Q, int P) { return P * (P + 1) / 2 + Q; }
 
-  // tile <-> compact exchange slot
-  ODEF_MF_FN void ex_put(double* __restrict__ ex, int u, const Geo& G, const d4& t) {
-    const int base = u * TSZ + G.g * TR + G.j;
+  // ------------------------------------------------------------------------------------------------ tile phases
+  // tiles -> compact exchange slots; the padding lanes of a tile store into a dummy area (no exec masking)
+  template <int WAVE>
+  ODEF_MF_FN void ex_put_all(const d4 (&T)[Own<WAVE>::nreg], const Geo& G0, double* __restrict__ ex) {
+    const Geo G = fresh(G0);
+    static_for<0, Own<WAVE>::n>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value;
+      constexpr int base = uidx(Own<WAVE>::tq(s), Own<WAVE>::tp(s)) * TSZ;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) ex[G.ok[v] ? base + 4 * v * TR : W::DUMMY + G.lane] = t[v];  // no exec masking
+      for (int v = 0; v < 4; ++v) {
+        double* p = G.ok[v] ? ex + base + (4 * v + G.g) * TR + G.j : ex + W::DUMMY + G.lane;
+        *p = T[s][v];
+      }
+    });
+  }
+
+  // first stage of predict_cov! (src/filtering.jl:33-41):  Z(Q, P) = sum_{k >= Q/2} At[Q/2][k] pj[k] pj[P/2] S(2k + Q%2, P),
+  // sources in the own tile COLUMN; those below the diagonal are read transposed (S symmetric), a diagonal one through
+  // its upper triangle (the rank updates leave rounding-level asymmetry there)
+  template <int WAVE>
+  ODEF_MF_FN void stage1(d4 (&T)[Own<WAVE>::nreg], const Geo& G0, const double* __restrict__ ex, const double* __restrict__ cf1) {
+    const Geo G = fresh(G0);
+    const double* dir = ex + G.g * TR + G.j;
+    const double* tra = ex + G.j * TR + G.g;
+    static_for<0, Own<WAVE>::n>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value;
+      constexpr int Q = Own<WAVE>::tq(s), P = Own<WAVE>::tp(s), a = Q >> 1, hq = Q & 1, b = P >> 1;
+      d4 acc = mf::zero4();
+      static_for<a, NB>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int Qs = 2 * k + hq;
+        const double c = cf1[(a * NB + b) * NB + k];
+        if constexpr (Qs < P) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[v] += c * dir[uidx(Qs, P) * TSZ + 4 * v * TR];
+        } else if constexpr (Qs == P) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[v] += c * ex[uidx(Qs, P) * TSZ + G.sym[v]];
+        } else {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[v] += c * tra[uidx(P, Qs) * TSZ + 4 * v];
+        }
+      });
+#pragma unroll
+      for (int v = 0; v < 4; ++v) T[s][v] = G.ok[v] ? acc[v] : 0.0;
+    });
+  }
+  // second stage:  S^-(Q, P) = sum_{k >= P/2} At[P/2][k] Z(Q, 2k + P%2)   (sigma2 Qt is added later), sources in the own tile ROW
+  template <int WAVE>
+  ODEF_MF_FN void stage2(d4 (&T)[Own<WAVE>::nreg], const Geo& G0, const double* __restrict__ ex, const double* __restrict__ cf2) {
+    const Geo G = fresh(G0);
+    const double* dir = ex + G.g * TR + G.j;
+    static_for<0, Own<WAVE>::n>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value;
+      constexpr int Q = Own<WAVE>::tq(s), P = Own<WAVE>::tp(s), b = P >> 1, hp = P & 1;
+      d4 acc = mf::zero4();
+      static_for<b, NB>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const double c = cf2[b * NB + k];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] += c * dir[uidx(Q, 2 * k + hp) * TSZ + 4 * v * TR];
+      });
+#pragma unroll
+      for (int v = 0; v < 4; ++v) T[s][v] = G.ok[v] ? acc[v] : 0.0;
+    });
+  }
+  // + sigma2 Q (src/filtering.jl:35): Qt[Q/2][P/2] on the diagonal of the tiles with equal halves
+  template <int WAVE>
+  ODEF_MF_FN void add_sigma2_q(d4 (&T)[Own<WAVE>::nreg], const Geo& G0, const PriorConsts& pc, double sigma2) {
+    const Geo G = fresh(G0);
+    static_for<0, Own<WAVE>::n>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value;
+      constexpr int Q = Own<WAVE>::tq(s), P = Own<WAVE>::tp(s);
+      if constexpr ((Q & 1) == (P & 1)) {
+        const double sq = sigma2 * pc.Qt[Q >> 1][P >> 1];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) T[s][v] += (G.ok[v] && 4 * v + G.g == G.j) ? sq : 0.0;
+      }
+    });
+  }
+
+  // the ten tiles of the first four tile columns, as full 16 x 16 row-major copies: the six above the diagonal (read
+  // back transposed by hproject) and the four diagonal ones (read back through their upper triangle by diag_resym)
+  template <int WAVE, bool WITH_DIAG>
+  ODEF_MF_FN void tl_put(const d4 (&T)[Own<WAVE>::nreg], const Geo& G0, double* __restrict__ tl) {
+    const Geo G = fresh(G0);
+    double* dst = tl + G.g * 16 + G.j;
+    static_for<0, Own<WAVE>::n>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value;
+      constexpr int Q = Own<WAVE>::tq(s), P = Own<WAVE>::tp(s);
+      if constexpr (P <= 3 && (Q < P || WITH_DIAG)) {
+        constexpr int id = Q < P ? P * (P - 1) / 2 + Q : 6 + Q;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dst[id * 256 + 64 * v] = T[s][v];
+      }
+    });
+  }
+  // A diagonal tile must be EXACTLY symmetric where it enters a product as a whole (H (.) tile): its antisymmetric part
+  // is not damped by the update but multiplied by (I + K H), step after step (numpy model in DESIGN.md section 3.9).
+  template <int WAVE>
+  ODEF_MF_FN void diag_resym(d4 (&T)[Own<WAVE>::nreg], const Geo& G0, const double* __restrict__ tl) {
+    const Geo G = fresh(G0);
+    static_for<0, Own<WAVE>::n>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value;
+      constexpr int Q = Own<WAVE>::tq(s), P = Own<WAVE>::tp(s);
+      if constexpr (Q == P && P <= 3) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int i = 4 * v + G.g;
+          T[s][v] = tl[(6 + Q) * 256 + (i < G.j ? i : G.j) * 16 + (i < G.j ? G.j : i)];
+        }
+      }
+    });
   }
 
   // (C_P)' = Hs' (.) over the tiles of the first two derivative blocks of every tile column, panel OUT[row][a]:
-  //   block 0 (tiles Q = 0, 1):  H0-part, 8 MFMAs per tile;  block 1 (tiles 2, 3):  h1 I, one FMA per element
-  ODEF_MF_FN void hproject(const d4 (&T)[NS], const Slots& S, const Geo& G0, const double* __restrict__ hs0,
+  //   block 0 (tiles Q = 0, 1):  H0-part, 8 MFMAs per tile;  block 1 (tiles 2, 3):  h1 I, one FMA per element.
+  // The panel is indexed by the PLAIN measurement index a (28 real columns + 4 zero ones: 7 k-steps in the rank updates
+  // instead of 8): row i of accumulator ta is a = 14 ta + i for i < 14; its two zero rows go to 28 + 2 ta + (i - 14).
+  template <int WAVE>
+  ODEF_MF_FN void hproject(const d4 (&T)[Own<WAVE>::nreg], const Geo& G0, const double* __restrict__ hs0,
                            const double* __restrict__ tl, double h1, double* __restrict__ out) {
     const Geo G = fresh(G0);
+    const double* hp = hs0 + G.g * LDP + G.j;
+    const double* tt = tl + G.j * 16 + G.g;
+    int oa[4], ob[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int i = 4 * v + G.g;
+      oa[v] = G.j * LDP + (i < TR ? i : 2 * TR + (i - TR));
+      ob[v] = G.j * LDP + (i < TR ? TR + i : 2 * TR + 2 + (i - TR));
+    }
     d4 acc0 = mf::zero4(), acc1 = mf::zero4();
-    static_for<0, NS>([&](auto sc_) {
+    static_for<0, Own<WAVE>::n>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
-      const int Q = S.tq[s], P = S.tp[s];
-      if (Q >= 0) {
-        if (Q <= 1) {
+      constexpr int Q = Own<WAVE>::tq(s), P = Own<WAVE>::tp(s);
+      if constexpr (Q <= 3) {
+        if constexpr (Q <= 1) {
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
-            const double* hp = hs0 + (16 * Q + 4 * ks + G.g) * LDP + G.j;
-            acc0 = mf::mfma(hp[0], T[s][ks], acc0);
-            acc1 = mf::mfma(hp[16], T[s][ks], acc1);
+            acc0 = mf::mfma(hp[(16 * Q + 4 * ks) * LDP], T[s][ks], acc0);
+            acc1 = mf::mfma(hp[(16 * Q + 4 * ks) * LDP + 16], T[s][ks], acc1);
           }
-        } else if (Q == 2) {
+        } else if constexpr (Q == 2) {
           acc0 += h1 * T[s];
-        } else if (Q == 3) {
+        } else {
           acc1 += h1 * T[s];
         }
-        if (Q == (P < 3 ? P : 3)) {  // last head tile of the column: the sources ABOVE the diagonal come transposed from the LDS copies
+        if constexpr (Q == (P < 3 ? P : 3)) {  // last head tile of the column: the sources ABOVE the diagonal come transposed from the LDS copies
+          static_for<P + 1, 4>([&](auto qc) {
+            constexpr int Qc = decltype(qc)::value;
+            constexpr int id = Qc * (Qc - 1) / 2 + P;
+            if constexpr (Qc == 1) {
 #pragma unroll
-          for (int Qc = 1; Qc <= 3; ++Qc) {
-            if (Qc > P) {
-              const double* tq = tl + (Qc * (Qc - 1) / 2 + P) * 256;
-              if (Qc == 1) {
+              for (int ks = 0; ks < 4; ++ks) {
+                const double b = tt[id * 256 + 4 * ks];
+                acc0 = mf::mfma(hp[(16 * Qc + 4 * ks) * LDP], b, acc0);
+                acc1 = mf::mfma(hp[(16 * Qc + 4 * ks) * LDP + 16], b, acc1);
+              }
+            } else {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                  const double* hp = hs0 + (16 * Qc + 4 * ks + G.g) * LDP + G.j;
-                  const double b = tq[G.j * 16 + 4 * ks + G.g];
-                  acc0 = mf::mfma(hp[0], b, acc0);
-                  acc1 = mf::mfma(hp[16], b, acc1);
-                }
-              } else {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                  const double x = h1 * tq[G.j * 16 + 4 * v + G.g];
-                  if (Qc == 2) acc0[v] += x; else acc1[v] += x;
-                }
+              for (int v = 0; v < 4; ++v) {
+                const double x = h1 * tt[id * 256 + 4 * v];
+                if constexpr (Qc == 2) acc0[v] += x; else acc1[v] += x;
               }
             }
-          }
-          // the panel is indexed by the PLAIN measurement index a (28 real columns + 4 zero ones: 7 k-steps in the rank
-          // updates instead of 8): row i of accumulator ta is a = 14 ta + i for i < 14; its two zero rows go to 28 + 2 ta + (i - 14)
-          double* o = out + (16 * P + G.j) * LDP;
+          });
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            const int i = 4 * v + G.g;
-            o[i < TR ? i : 2 * TR + (i - TR)] = acc0[v];
-            o[i < TR ? TR + i : 2 * TR + 2 + (i - TR)] = acc1[v];
+            out[16 * P * LDP + oa[v]] = acc0[v];
+            out[16 * P * LDP + ob[v]] = acc1[v];
           }
           acc0 = mf::zero4();
           acc1 = mf::zero4();
@@ -259,64 +399,31 @@ struct MfmaFilter {
     });
   }
 
-  // the ten tiles of the first four tile columns, as full 16 x 16 row-major copies: the six above the diagonal (read
-  // back transposed by hproject) and the four diagonal ones (read back through their upper triangle by diag_resym)
-  ODEF_MF_FN void tl_put(const d4 (&T)[NS], const Slots& S, const Geo& G0, double* __restrict__ tl, bool with_diag) {
+  // T[s] -= A_panel[tile row Q] B_panel[tile row P]'  (rank-d update of every tile), then T[s] *= scale[Q/2][P/2] if given
+  template <int WAVE, bool SCALE>
+  ODEF_MF_FN void rank_update(d4 (&T)[Own<WAVE>::nreg], const Geo& G0, const double* __restrict__ ap,
+                              const double* __restrict__ bp, const double* __restrict__ scale) {
     const Geo G = fresh(G0);
-    static_for<0, NS>([&](auto sc_) {
-      constexpr int s = decltype(sc_)::value;
-      const int Q = S.tq[s], P = S.tp[s];
-      if (Q >= 0 && P <= 3 && (Q < P || with_diag)) {
-        double* dst = tl + (Q < P ? P * (P - 1) / 2 + Q : 6 + Q) * 256 + G.g * 16 + G.j;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) dst[64 * v] = T[s][v];
-      }
-    });
-  }
-  // A diagonal tile must be EXACTLY symmetric where it enters a product as a whole (H (.) tile): its antisymmetric part
-  // is not damped by the update but multiplied by (I + K H), step after step (numpy model in DESIGN.md section 3.9).
-  ODEF_MF_FN void diag_resym(d4 (&T)[NS], const Slots& S, const Geo& G0, const double* __restrict__ tl) {
-    const Geo G = fresh(G0);
-    static_for<0, NS>([&](auto sc_) {
-      constexpr int s = decltype(sc_)::value;
-      const int Q = S.tq[s], P = S.tp[s];
-      if (Q >= 0 && Q == P && P <= 3) {
-        const double* src = tl + (6 + Q) * 256;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int i = 4 * v + G.g;
-          T[s][v] = src[(i < G.j ? i : G.j) * 16 + (i < G.j ? G.j : i)];
-        }
-      }
-    });
-  }
-
-  static constexpr int KS = (d + 3) / 4;  // k-steps of a product over the measurement index
-  // T[s] -= A_panel[tile row Q] B_panel[tile row P]'  (rank-d update of every tile)
-  ODEF_MF_FN void rank_update(d4 (&T)[NS], const Slots& S, const Geo& G0, const double* __restrict__ ap,
-                              const double* __restrict__ bp) {
-    const Geo G = fresh(G0);
+    const double* a = ap + G.j * LDP + G.g;
+    const double* b = bp + G.j * LDP + G.g;
     double bf[KS];
-    static_for<0, NS>([&](auto sc_) {
+    static_for<0, Own<WAVE>::n>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
-      const int Q = S.tq[s], P = S.tp[s];
-      if (Q >= 0) {
-        bool reload = true;
-        if constexpr (s > 0) reload = S.tp[s - 1] != P;
-        if (reload) {  // first tile of a run of one column: its B fragments (negated: the product is subtracted)
-          const double* b = bp + (16 * P + G.j) * LDP + G.g;
+      constexpr int Q = Own<WAVE>::tq(s), P = Own<WAVE>::tp(s);
+      constexpr bool reload = s == 0 || Own<WAVE>::tp(s > 0 ? s - 1 : 0) != P;
+      if constexpr (reload) {  // first tile of a run of one column: its B fragments (negated: the product is subtracted)
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) bf[ks] = -b[4 * ks];
-        }
-        const double* a = ap + (16 * Q + G.j) * LDP + G.g;
-        d4 acc = T[s];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = mf::mfma(a[4 * ks], bf[ks], acc);
-        T[s] = acc;
+        for (int ks = 0; ks < KS; ++ks) bf[ks] = -b[16 * P * LDP + 4 * ks];
       }
+      d4 acc = T[s];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = mf::mfma(a[16 * Q * LDP + 4 * ks], bf[ks], acc);
+      if constexpr (SCALE) acc *= scale[(Q >> 1) * MAXNB + (P >> 1)];
+      T[s] = acc;
     });
   }
 
+  // ------------------------------------------------------------------------------------------------ helper pieces
   // Cholesky of a 32 x 32 (28 real, plain index: 16 + 12) SPD matrix in two 16 x 16 blocks, by one wavefront:
   //   sb11 / sb22: the diagonal blocks (+ 16 reciprocal pivots behind each), sb21: the block below them (row-major [16][16])
   //   out: w11 / w22 = inverses of the two diagonal factors (pitch ldw), l21 = L21 [16][16]
@@ -362,113 +469,164 @@ struct MfmaFilter {
     for (int v = 0; v < 4; ++v) wl[(16 + 4 * v + G.g) * LDP + G.j] = w21[v];
     tv::lds_sync();
   }
-  // sum over the wavefront
   ODEF_MF_FN double wave_sum(double x) {
 #pragma unroll
     for (int msk = 32; msk >= 1; msk >>= 1) x += __shfl_xor(x, msk, 64);
     return x;
   }
 
-  // ---------------------------------------------------------------------------------------------------------- step
-  // Compiled twice from the same source (as filter_tiles.h): HELPER = the wavefront without tiles.  Both instantiations
-  // execute the same number of barriers; neither carries the other's registers.
-  template <bool HELPER>
-  ODEF_MF_FN void step(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab, int fixed_diffusion,
-                       int success_iter, double* __restrict__ sm, d4 (&T)[NS], const Slots& S, const Geo& G0, int tid, int wave) {
-    Geo G = fresh(G0);
-    double* ex = sm + W::EX;
-    double* vp = sm + W::VP;
-    double* kp = sm + W::KP;
-    double* tl = sm + W::TL;
+  // ---- the measurement chain of a step, by ONE wavefront (the helper), with wave-level LDS fences only: everything
+  // that depends on the mean alone -- m^- = A P m, u_pred, f, J, z, H0, M0, W = H Q H', the padded H0' and the
+  // coefficient tables of the congruence (src/perform_step.jl:36-43,95-132, src/diffusions.jl:78).  It runs for step
+  // n + 1 beside the tail of step n, so that a step of the tile wavefronts starts with the congruence right away.
+  ODEF_MF_FN void chain_a1(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab,
+                           double* __restrict__ sm, int lane) {
     double* H0 = sm + W::H0;
-    double* M0 = sm + W::M0;
     double* WM = sm + W::WM;
-    double* wl = sm + W::WL;
-    double* hs0 = sm + W::HS0;
     double* m = sm + W::MV;
     double* mt = sm + W::MT;
     double* mp = sm + W::MP;
-    double* z = sm + W::Z;
-    double* y = sm + W::YV;
     double* up = sm + W::UP;
     double* du = sm + W::DU;
-    double* sc = sm + W::SC;
-    const double pi0 = tab[kTabPIJ + 0], pi1 = tab[kTabPIJ + 1], h1 = pi1;
-
-    ODEF_MF_STAMP(0)
-    // x~ = P x (src/perform_step.jl:36-38): the covariance tiles go to the exchange as they are, the scaling is folded
-    // into the coefficients of the congruence
-    if (tid < D) mt[tid] = tab[kTabPJ + tid / d] * m[tid];
-    if constexpr (HELPER) {  // coefficient tables of the congruence (read as LDS broadcasts: no scalar loads inside the tile loops)
-      for (int e = G.lane; e < NB * NB * NB; e += 64) {
-        const int a = e / (NB * NB), b = (e / NB) % NB, k = e % NB;
-        sm[W::CF1 + e] = pc.At[a][k] * (tab[kTabPJ + k] * tab[kTabPJ + b]);
-      }
-      for (int e = G.lane; e < NB * NB; e += 64) sm[W::CF2 + e] = pc.At[e / NB][e % NB];
-    }
-    if constexpr (!HELPER) {
-      static_for<0, NS>([&](auto sc_) {
-        constexpr int s = decltype(sc_)::value;
-        if (S.tq[s] >= 0) ex_put(ex, uidx(S.tq[s], S.tp[s]), G, T[s]);
-      });
-    }
-    __syncthreads();
-    // m^- = A m~ , u_pred  (src/filtering.jl:22-25, src/perform_step.jl:43)
-    if (tid < D) {
-      const int J = tid / d, a = tid % d;
-      double s = mt[tid];
+    double* tabL = sm + W::TAB;  // the step's preconditioner table in LDS: per-lane indices into it below
+    for (int e = lane; e < kTabStride; e += 64) tabL[e] = tab[e];
+    tv::lds_sync();
+    for (int r = lane; r < D; r += 64) mt[r] = tabL[kTabPJ + r / d] * m[r];
+    tv::lds_sync();
+    const double pi0 = tabL[kTabPIJ + 0];
+    for (int r = lane; r < D; r += 64) {
+      const int J = r / d, a = r % d;
+      double s = mt[r];
       for (int j = J + 1; j < NB; ++j) s += pc.At[J][j] * mt[j * d + a];
-      mp[tid] = s;
-      if (tid < d) up[tid] = pi0 * s;
+      mp[r] = s;
+      if (r < d) up[r] = pi0 * s;
     }
-    __syncthreads();
-    ODEF_MF_STAMP(1)
-    // measure! (src/perform_step.jl:95-132)
+    tv::lds_sync();
     if constexpr (HasTeamEval<RHS>::value) {
       static_assert(RHS::team_scratch <= d * W::LDd, "pair buffer must fit the W area");
-      RHS::team_eval_pairs(tid, up, WM);
-      __syncthreads();
-      RHS::team_eval_assemble(tid, NTHR, up, WM, du, IS_EK1 ? H0 : nullptr);  // raw J into H0, scaled below
-      __syncthreads();
+      RHS::team_eval_pairs(lane, up, WM);
+      tv::lds_sync();
+      RHS::team_eval_assemble(lane, 64, up, WM, du, IS_EK1 ? H0 : nullptr);  // raw J into H0, scaled in chain_a2
     } else {
-      if (tid == 0) {
+      if (lane == 0) {
         double u_[d], du_[d];
         for (int a = 0; a < d; ++a) u_[a] = up[a];
         RHS::f(u_, p, du_);
         for (int a = 0; a < d; ++a) du[a] = du_[a];
         if constexpr (IS_EK1) RHS::jac(u_, p, *reinterpret_cast<double (*)[d][d]>(H0));
       }
-      __syncthreads();
     }
-    ODEF_MF_STAMP(2)
-    if (tid < d) z[tid] = pi1 * mp[d + tid] - du[tid];
-    for (int e = tid; e < d * d; e += NTHR) {  // H0 = -J pi0 ; M0 = H0 QL00 + I h1 QL10 (src/diffusions.jl:78)
-      const int r = e / d, a = e % d;
-      double h0 = 0.0;
-      if constexpr (IS_EK1) h0 = (0.0 - H0[e]) * pi0;
-      H0[e] = h0;
-      M0[e] = h0 * pc.QLt[0][0] + (r == a ? h1 * pc.QLt[1][0] : 0.0);
-    }
-    __syncthreads();
-    {
-      const double m1 = h1 * pc.QLt[1][1];
-      for (int e = tid; e < d * d; e += NTHR) {
-        const int r = e / d, s_ = e % d;
-        double acc = (r == s_) ? m1 * m1 : 0.0;
-        for (int a = 0; a < d; ++a) acc += M0[r * d + a] * M0[s_ * d + a];
-        WM[r * W::LDd + s_] = acc;
-        if (r == s_) sm[W::WD + r] = acc;  // diag(H Q H') for the error estimate (src/perform_step.jl:148-158)
-      }
-      for (int e = tid; e < 32 * LDP; e += NTHR) {  // Hs0[k][a] = H0[a][k] in padded (tile) indices, zero elsewhere
-        const int kp_ = e / LDP, ap_ = e % LDP;
-        double v = 0.0;
-        if (ap_ < 32 && (kp_ & 15) < TR && (ap_ & 15) < TR) v = H0[((ap_ >> 4) * TR + (ap_ & 15)) * d + (kp_ >> 4) * TR + (kp_ & 15)];
-        hs0[e] = v;
+    tv::lds_sync();
+  }
+  ODEF_MF_FN void chain_a2(const PriorConsts& pc, double* __restrict__ sm, int lane) {
+    double* H0 = sm + W::H0;
+    double* M0 = sm + W::M0;
+    const double* mp = sm + W::MP;
+    const double* du = sm + W::DU;
+    double* z = sm + W::Z;
+    const double* tabL = sm + W::TAB;
+    const double pi0 = tabL[kTabPIJ + 0], pi1 = tabL[kTabPIJ + 1], h1 = pi1;
+    if (lane < d) z[lane] = pi1 * mp[d + lane] - du[lane];
+    const double ql00 = pc.QLt[0][0], dg = h1 * pc.QLt[1][0];
+    for (int r = lane >> 2; r < d; r += 16) {  // H0 = -J pi0 ; M0 = H0 QL00 + I h1 QL10 (src/diffusions.jl:78): row r, columns lane % 4 + 4 t
+#pragma unroll
+      for (int t = 0; t < KS; ++t) {
+        const int a = (lane & 3) + 4 * t;
+        if (a < d) {
+          double h0 = 0.0;
+          if constexpr (IS_EK1) h0 = (0.0 - H0[r * d + a]) * pi0;
+          H0[r * d + a] = h0;
+          M0[r * d + a] = h0 * ql00 + (r == a ? dg : 0.0);
+        }
       }
     }
+    tv::lds_sync();
+  }
+  // W = M0 M0' + (h1 QL11)^2 I on the matrix pipe (lower blocks), diag(W) for the error estimate, coefficient tables
+  ODEF_MF_FN void chain_b(const PriorConsts& pc, bool new_table, double* __restrict__ sm, const Geo& G) {
+    const double* M0 = sm + W::M0;
+    double* WM = sm + W::WM;
+    const double* tabL = sm + W::TAB;
+    const double h1 = tabL[kTabPIJ + 1], m1 = h1 * pc.QLt[1][1];
+    static_for<0, 3>([&](auto bc) {
+      constexpr int blk = decltype(bc)::value;  // 0: (0,0)  1: (1,0)  2: (1,1)
+      constexpr int ta = blk >= 1, tb = blk == 2;
+      const int ra = 16 * ta + G.j, rb = 16 * tb + G.j;
+      d4 acc = mf::zero4();
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + G.g;
+        const double fa = (ra < d && k < d) ? M0[ra * d + k] : 0.0;
+        const double fb = (rb < d && k < d) ? M0[rb * d + k] : 0.0;
+        acc = mf::mfma(fa, fb, acc);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int a = 16 * ta + 4 * v + G.g, b = 16 * tb + G.j;
+        if (a < d && b < d) {
+          const double w = acc[v] + (a == b ? m1 * m1 : 0.0);
+          WM[a * W::LDd + b] = w;
+          if (a == b) sm[W::WD + a] = w;  // diag(H Q H') for the error estimate (src/perform_step.jl:148-158)
+        }
+      }
+    });
+    if (new_table) {  // the coefficient tables change with the step size only
+      for (int e = G.lane; e < NB * NB * NB; e += 64) {
+        const int a = e / (NB * NB), b = (e / NB) % NB, k = e % NB;
+        sm[W::CF1 + e] = pc.At[a][k] * (tabL[kTabPJ + k] * tabL[kTabPJ + b]);
+      }
+      for (int e = G.lane; e < NB * NB; e += 64) sm[W::CF2 + e] = pc.At[e / NB][e % NB];
+    }
+    tv::lds_sync();
+  }
+  // Hs0[k][a] = H0[a][k] in padded (tile) indices, zero elsewhere -- only once E = T H' of the running step is done
+  ODEF_MF_FN void chain_c(double* __restrict__ sm, int lane) {
+    const double* H0 = sm + W::H0;
+    double* hs0 = sm + W::HS0;
+    const int ap_ = lane & 31, a = (ap_ >> 4) * TR + (ap_ & 15);
+    const bool a_ok = (ap_ & 15) < TR;
+#pragma unroll 4
+    for (int kp_ = lane >> 5; kp_ < 32; kp_ += 2) {
+      const bool ok = a_ok && (kp_ & 15) < TR;
+      hs0[kp_ * LDP + ap_] = ok ? H0[a * d + (kp_ >> 4) * TR + (kp_ & 15)] : 0.0;
+    }
+    if (lane < 32) {  // the two pitch columns
+      hs0[lane * LDP + 32] = 0.0;
+      hs0[lane * LDP + 33] = 0.0;
+    }
+    tv::lds_sync();
+  }
+
+  // ---------------------------------------------------------------------------------------------------------- step
+  // One instantiation per wavefront: WAVE < kMfTileWaves for the tile wavefronts, WAVE == kMfHelper for the helper.  All
+  // instantiations execute the same sequence of barriers; none carries another's registers.
+  template <int WAVE>
+  ODEF_MF_FN void step(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab,
+                       const double* __restrict__ tab_next /* null after the last step */, int fixed_diffusion, int success_iter,
+                       double* __restrict__ sm, d4 (&T)[Own<WAVE>::nreg], const Geo& G0, int tid) {
+    constexpr bool HELPER = WAVE == kMfHelper;
+    Geo G = fresh(G0);
+    double* ex = sm + W::EX;
+    double* vp = sm + W::VP;
+    double* kp = sm + W::KP;
+    double* tl = sm + W::TL;
+    double* WM = sm + W::WM;
+    double* wl = sm + W::WL;
+    double* hs0 = sm + W::HS0;
+    double* m = sm + W::MV;
+    double* mp = sm + W::MP;
+    double* z = sm + W::Z;
+    double* y = sm + W::YV;
+    double* sc = sm + W::SC;
+    const double h1 = tab[kTabPIJ + 1];
+    (void)m; (void)mp; (void)z; (void)y; (void)WM; (void)wl; (void)kp; (void)tl; (void)ex; (void)p; (void)success_iter; (void)tab_next;
+
+    ODEF_MF_STAMP(0)
+    // x~ = P x (src/perform_step.jl:36-38): the covariance tiles go to the exchange as they are, the scaling is folded
+    // into the coefficients of the congruence.  Mean, measurement and H Q H' of this step are already there (chain_*).
+    if constexpr (!HELPER) ex_put_all<WAVE>(T, G0, ex);
     __syncthreads();
     ODEF_MF_STAMP(3)
-    G = fresh(G0);
     if constexpr (HELPER) {
       // sigma^2 = z' W^-1 z / d (src/diffusions.jl:72-80): blocked Cholesky of W = H Q H' beside the congruence of the
       // others -- first half here, second half beside stage 2
@@ -483,51 +641,16 @@ struct MfmaFilter {
           c22[e] = (16 + r < d && 16 + c < d) ? WM[(16 + r) * W::LDd + 16 + c] : 0.0;
         }
         tv::lds_sync();
+        ODEF_MF_HSTAMP(0)
         chol2_a(c11, c22, c21, sm + W::CWL, sm + W::CWW1, 16, G);
+        ODEF_MF_HSTAMP(1)
       }
     } else {
-      // predict_cov! (src/filtering.jl:33-41) in two stages through the tile exchange, whole tiles onto whole tiles:
-      //   Z(Q, P) = sum_{k >= Q/2} At[Q/2][k] pj[k] pj[P/2] S(2k + Q%2, P)     sources in the own tile COLUMN; those below the
-      //                                                                        diagonal are read transposed (S symmetric)
-      //   S^-(Q, P) = sum_{k >= P/2} At[P/2][k] Z(Q, 2k + P%2)  ( + sigma2 Qt later )   sources in the own tile ROW, all kept
-      static_for<0, NS>([&](auto sc_) {
-        constexpr int s = decltype(sc_)::value;
-        const int Q = S.tq[s], P = S.tp[s];
-        if (Q >= 0) {
-          const int a = Q >> 1, hq = Q & 1, b = P >> 1;
-          const double* cf = sm + W::CF1 + (a * NB + b) * NB;
-          d4 acc = mf::zero4();
-          for (int k = a; k < NB; ++k) {
-            const int Qs = 2 * k + hq;
-            const double coef = cf[k];
-            if (Qs < P) {
-              const double* src = ex + uidx(Qs, P) * TSZ + G.g * TR + G.j;
-#pragma unroll
-              for (int v = 0; v < 4; ++v) acc[v] += coef * src[4 * v * TR];
-            } else if (Qs == P) {  // a diagonal tile is its upper triangle (the rank updates leave rounding-level asymmetry)
-              const double* src = ex + uidx(Qs, P) * TSZ;
-#pragma unroll
-              for (int v = 0; v < 4; ++v) acc[v] += coef * src[G.sym[v]];
-            } else {
-              const double* src = ex + uidx(P, Qs) * TSZ + G.j * TR + G.g;
-#pragma unroll
-              for (int v = 0; v < 4; ++v) acc[v] += coef * src[4 * v];
-            }
-          }
-#pragma unroll
-          for (int v = 0; v < 4; ++v) T[s][v] = G.ok[v] ? acc[v] : 0.0;
-        }
-      });
+      stage1<WAVE>(T, G0, ex, sm + W::CF1);
     }
     __syncthreads();
     ODEF_MF_STAMP(4)
-    G = fresh(G0);
-    if constexpr (!HELPER) {
-      static_for<0, NS>([&](auto sc_) {
-        constexpr int s = decltype(sc_)::value;
-        if (S.tq[s] >= 0) ex_put(ex, uidx(S.tq[s], S.tp[s]), G, T[s]);
-      });
-    }
+    if constexpr (!HELPER) ex_put_all<WAVE>(T, G0, ex);
     __syncthreads();
     ODEF_MF_STAMP(5)
     G = fresh(G0);
@@ -535,56 +658,47 @@ struct MfmaFilter {
       if (!fixed_diffusion) {
         double* w1 = sm + W::CWW1;
         double* w2 = sm + W::CWW2;
+        ODEF_MF_HSTAMP(0)
         chol2_b(sm + W::CW22, w2, 16);
+        ODEF_MF_HSTAMP(2)
         // y = L^-1 z: y1 = W11 z1, y2 = W22 (z2 - L21 y1); lanes 0..15 hold y1, lanes 16..31 hold y2
         const int l = G.lane, r = l & 15;
         double y1 = 0.0;
-        for (int b = 0; b <= r; ++b) y1 += w1[r * 16 + b] * z[b];
+#pragma unroll
+        for (int b = 0; b < 16; ++b) y1 += w1[r * 16 + b] * z[b];  // the inverses are lower triangular: fixed trip counts
         double t2 = z[16 + r];  // zero beyond d
+#pragma unroll
         for (int b = 0; b < 16; ++b) t2 -= sm[W::CWL + r * 16 + b] * __shfl(y1, b, 64);
         double y2 = 0.0;
-        for (int b = 0; b <= r; ++b) y2 += w2[r * 16 + b] * __shfl(t2, b, 64);
+#pragma unroll
+        for (int b = 0; b < 16; ++b) y2 += w2[r * 16 + b] * __shfl(t2, b, 64);
         const double acc = wave_sum(l < 16 ? y1 * y1 : l < 32 ? y2 * y2 : 0.0);
         if (l == 0) {
           sc[0] = acc / d;
           sc[4] = acc / d;
         }
+        ODEF_MF_HSTAMP(3)
       }
     } else {
-      static_for<0, NS>([&](auto sc_) {
-        constexpr int s = decltype(sc_)::value;
-        const int Q = S.tq[s], P = S.tp[s];
-        if (Q >= 0) {
-          const int b = P >> 1, hp = P & 1;
-          d4 acc = mf::zero4();
-          const double* cf = sm + W::CF2 + b * NB;
-          for (int k = b; k < NB; ++k) {
-            const double coef = cf[k];
-            const double* src = ex + uidx(Q, 2 * k + hp) * TSZ + G.g * TR + G.j;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[v] += coef * src[4 * v * TR];
-          }
-#pragma unroll
-          for (int v = 0; v < 4; ++v) T[s][v] = G.ok[v] ? acc[v] : 0.0;
-        }
-      });
+      stage2<WAVE>(T, G0, ex, sm + W::CF2);
     }
     __syncthreads();  // the exchange is dead: region R0 now holds the panels
     ODEF_MF_STAMP(6)
-    if constexpr (!HELPER) tl_put(T, S, G0, tl, true);
+    if constexpr (!HELPER) tl_put<WAVE, true>(T, G0, tl);
     __syncthreads();
     ODEF_MF_STAMP(7)
     if constexpr (!HELPER) {
-      diag_resym(T, S, G0, tl);
-      hproject(T, S, G0, hs0, tl, h1, vp);  // C0 = (A S A') H' into the V panel
+      diag_resym<WAVE>(T, G0, tl);
+      hproject<WAVE>(T, G0, hs0, tl, h1, vp);  // C0 = (A S A') H' into the V panel
     }
     __syncthreads();  // ... and sigma^2 is there
     ODEF_MF_STAMP(8)
     G = fresh(G0);
     const double sigma2_pred = fixed_diffusion ? 1.0 : sc[0];
     if constexpr (HELPER) {
-      // Sm = H C = H C0 + sigma2 H Q H' (d x d, plain index): the three blocks of its lower triangle, then its Cholesky,
-      // W = L^-1, y = W z, z'Sm^-1 z and log det Sm (src/perform_step.jl:66)
+      ODEF_MF_HSTAMP(0)
+      // Sm = H C = H C0 + sigma2 H Q H' (d x d, plain index): the three blocks of its lower triangle, then its Cholesky
+      // and W = L^-1 (src/perform_step.jl:66, src/filtering.jl:84-85)
       static_for<0, 3>([&](auto bc) {
         constexpr int blk = decltype(bc)::value;  // 0: (0,0)  1: (1,0)  2: (1,1)
         constexpr int ta = blk >= 1, tb = blk == 2;
@@ -604,11 +718,22 @@ struct MfmaFilter {
         }
       });
       tv::lds_sync();
+      ODEF_MF_HSTAMP(4)
       factor_s(sm + W::SB11, sm + W::SB22, sm + W::SB21, sm + W::L21, wl, G);
+      ODEF_MF_HSTAMP(5)
+    } else {
+      add_sigma2_q<WAVE>(T, G0, pc, sigma2_pred);
+    }
+    __syncthreads();
+    ODEF_MF_STAMP(10)
+    G = fresh(G0);
+    if constexpr (HELPER) {  // y = W z, z'Sm^-1 z, log det Sm: beside the V / K products of the others (y is read after the next barrier)
+      ODEF_MF_HSTAMP(0)
       const int l = G.lane;
       double yv = 0.0, lg = 0.0;
       if (l < 32) {
-        for (int b = 0; b <= l; ++b) yv += wl[l * LDP + b] * z[b];
+#pragma unroll
+        for (int b = 0; b < 32; ++b) yv += wl[l * LDP + b] * z[b];  // W_S is lower triangular, z is zero beyond d: fixed trip count
         const double rp = (l < 16) ? sm[W::SB11 + 256 + l] : sm[W::SB22 + 256 + l - 16];
         lg = (rp > 0.0) ? -log(rp) : 0.0;
         y[l] = yv;
@@ -624,64 +749,58 @@ struct MfmaFilter {
           sc[4] = static_diffusion_update<d>(fixed_diffusion, success_iter, prev, dt_);
         }
       }
+      ODEF_MF_HSTAMP(6)
     } else {
-      // + sigma2 Q on the tiles (src/filtering.jl:35): Qt[Q/2][P/2] on the diagonal of the tiles with equal halves
-      static_for<0, NS>([&](auto sc_) {
-        constexpr int s = decltype(sc_)::value;
-        const int Q = S.tq[s], P = S.tp[s];
-        if (Q >= 0 && (Q & 1) == (P & 1)) {
-          const double sq = sigma2_pred * pc.Qt[Q >> 1][P >> 1];
+      // per tile row R of the panels, one wavefront: C = C0 + sigma2 Q H', then V = C W' (in place) and K = V W
+      for (int R = WAVE; R < NT; R += kMfTileWaves) {
+        {
+          const int bq = R >> 1, hr = R & 1;
+          const double q0 = sigma2_pred * pc.Qt[bq][0], q1 = sigma2_pred * pc.Qt[bq][1] * h1;
+          // (Q H')[r][a] = Qt[b][0] H0[a][i] + Qt[b][1] h1 [a == i],  r = (b, i): lane -> row ii = lane / 4, columns lane % 4 + 4 t
+          const int ii = G.lane >> 2, a0 = G.lane & 3;
+          if (ii < TR) {
+            const int i = TR * hr + ii;
+            double* row = vp + (16 * R + ii) * LDP;
+            const double* hrow = hs0 + pad_d(i) * LDP;
 #pragma unroll
-          for (int v = 0; v < 4; ++v) T[s][v] += (G.ok[v] && 4 * v + G.g == G.j) ? sq : 0.0;
+            for (int t = 0; t < KS; ++t) {
+              const int a = a0 + 4 * t;
+              if (a < d) row[a] += q0 * hrow[a < TR ? a : a + 16 - TR] + (a == i ? q1 : 0.0);
+            }
+          }
         }
-      });
-    }
-    __syncthreads();
-    ODEF_MF_STAMP(10)
-    G = fresh(G0);
-    // per tile row R of the panels, one wavefront: C = C0 + sigma2 Q H', then V = C W' (in place) and K = V W
-    for (int R = wave; R < NT; R += kMfWaves) {
-      {
-        const int bq = R >> 1, hr = R & 1;
-        const double q0 = sigma2_pred * pc.Qt[bq][0], q1 = sigma2_pred * pc.Qt[bq][1] * h1;
-        for (int e = G.lane; e < TR * d; e += 64) {  // (Q H')[r][a] = Qt[b][0] H0[a][i] + Qt[b][1] h1 [a == i],  r = (b, i)
-          const int ii = e / d, a = e % d, i = TR * hr + ii;
-          double x = q0 * hs0[pad_d(i) * LDP + pad_d(a)];
-          if (a == i) x += q1;
-          vp[(16 * R + ii) * LDP + a] += x;
+        tv::lds_sync();
+        // W_S is lower triangular: the k-steps that meet only its zero blocks are skipped (21 products instead of 28)
+        d4 v0 = mf::zero4(), v1 = mf::zero4();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const double a = vp[(16 * R + G.j) * LDP + 4 * ks + G.g];
+          if (ks < 4) v0 = mf::mfma(a, wl[G.j * LDP + 4 * ks + G.g], v0);  // V[:, j < 16] = sum_{k <= j} C[:, k] W[j][k]
+          v1 = mf::mfma(a, wl[(16 + G.j) * LDP + 4 * ks + G.g], v1);
         }
-      }
-      tv::lds_sync();
-      d4 v0 = mf::zero4(), v1 = mf::zero4();
+        tv::lds_sync();
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const double a = vp[(16 * R + G.j) * LDP + 4 * ks + G.g];
-        v0 = mf::mfma(a, wl[G.j * LDP + 4 * ks + G.g], v0);
-        v1 = mf::mfma(a, wl[(16 + G.j) * LDP + 4 * ks + G.g], v1);
-      }
-      tv::lds_sync();
+        for (int v = 0; v < 4; ++v) {
+          vp[(16 * R + 4 * v + G.g) * LDP + G.j] = v0[v];
+          vp[(16 * R + 4 * v + G.g) * LDP + 16 + G.j] = v1[v];
+        }
+        tv::lds_sync();
+        d4 k0 = mf::zero4(), k1 = mf::zero4();
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        vp[(16 * R + 4 * v + G.g) * LDP + G.j] = v0[v];
-        vp[(16 * R + 4 * v + G.g) * LDP + 16 + G.j] = v1[v];
-      }
-      tv::lds_sync();
-      d4 k0 = mf::zero4(), k1 = mf::zero4();
+        for (int ks = 0; ks < KS; ++ks) {
+          const double a = vp[(16 * R + G.j) * LDP + 4 * ks + G.g];
+          k0 = mf::mfma(a, wl[(4 * ks + G.g) * LDP + G.j], k0);
+          if (ks >= 4) k1 = mf::mfma(a, wl[(4 * ks + G.g) * LDP + 16 + G.j], k1);  // K[:, j >= 16] = sum_{k >= j} V[:, k] W[k][j]
+        }
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const double a = vp[(16 * R + G.j) * LDP + 4 * ks + G.g];
-        k0 = mf::mfma(a, wl[(4 * ks + G.g) * LDP + G.j], k0);
-        k1 = mf::mfma(a, wl[(4 * ks + G.g) * LDP + 16 + G.j], k1);
-      }
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        kp[(16 * R + 4 * v + G.g) * LDP + G.j] = k0[v];
-        kp[(16 * R + 4 * v + G.g) * LDP + 16 + G.j] = k1[v];
+        for (int v = 0; v < 4; ++v) {
+          kp[(16 * R + 4 * v + G.g) * LDP + G.j] = k0[v];
+          kp[(16 * R + 4 * v + G.g) * LDP + 16 + G.j] = k1[v];
+        }
       }
     }
     __syncthreads();
     ODEF_MF_STAMP(11)
-    G = fresh(G0);
     // m = m^- - V y (src/filtering.jl:87), un-preconditioned (src/perform_step.jl:75);  T = S^- - V V'
     if (tid < D) {
       const int prow = 32 * (tid / d) + pad_d(tid % d);
@@ -690,113 +809,122 @@ struct MfmaFilter {
       for (int a = 0; a < d; ++a) s -= vp[prow * LDP + a] * y[a];
       m[tid] = tab[kTabPIJ + tid / d] * s;
     }
-    if constexpr (!HELPER) rank_update(T, S, G0, vp, vp);  // bitwise symmetric on the diagonal tiles (same products, same order)
+    if constexpr (!HELPER) {
+      rank_update<WAVE, false>(T, G0, vp, vp, nullptr);  // bitwise symmetric on the diagonal tiles (same products, same order)
+      tl_put<WAVE, false>(T, G0, tl);                     // ... and the copies of the first-column tiles for E = T H'
+    }
     __syncthreads();
     ODEF_MF_STAMP(12)
-    if constexpr (!HELPER) tl_put(T, S, G0, tl, false);
-    __syncthreads();
-    ODEF_MF_STAMP(13)
-    if constexpr (!HELPER) hproject(T, S, G0, hs0, tl, h1, vp);  // E = T H' over the V panel
+    if constexpr (HELPER) {
+      ODEF_MF_HSTAMP(0)
+      if (tab_next) chain_a1(pc, p, tab_next, sm, G0.lane);  // the next step's measurement chain beside the rest of this step
+      ODEF_MF_HSTAMP(7)
+    } else {
+      hproject<WAVE>(T, G0, hs0, tl, h1, vp);  // E = T H' over the V panel
+    }
     __syncthreads();
     ODEF_MF_STAMP(14)
-    if constexpr (!HELPER) {
-      rank_update(T, S, G0, vp, kp);  // S = T - E K'
-      static_for<0, NS>([&](auto sc_) {  // un-precondition (src/perform_step.jl:73-75)
-        constexpr int s = decltype(sc_)::value;
-        if (S.tq[s] >= 0) T[s] *= tab[kTabPIPI + (S.tq[s] >> 1) * MAXNB + (S.tp[s] >> 1)];
-      });
+    if constexpr (HELPER) {
+      if (tab_next) {
+        ODEF_MF_HSTAMP(0)
+        chain_a2(pc, sm, G0.lane);
+        ODEF_MF_HSTAMP(8)
+        chain_b(pc, tab_next != tab, sm, fresh(G0));
+        ODEF_MF_HSTAMP(9)
+        chain_c(sm, G0.lane);
+        ODEF_MF_HSTAMP(10)
+      }
+    } else {
+      rank_update<WAVE, true>(T, G0, vp, kp, tab + kTabPIPI);  // S = T - E K', un-preconditioned (src/perform_step.jl:73-75)
     }
     __syncthreads();
     ODEF_MF_STAMP(15)
   }
 
-  template <bool HELPER>
+  // one saved record: mean, packed covariance (own tiles), diffusion
+  template <int WAVE>
   ODEF_MF_FN void save_record(const FilterParams& P, long i, long slot, double diffusion, const double* __restrict__ sm,
-                              const d4 (&T)[NS], const Slots& S, const Geo& G, int tid) {
+                              const d4 (&T)[Own<WAVE>::nreg], const Geo& G, int tid) {
     const double* m = sm + W::MV;
     const size_t N = (size_t)P.N;
     if (tid < D) P.mean[((size_t)slot * D + tid) * N + i] = m[tid];
-    if constexpr (!HELPER) {
-      static_for<0, NS>([&](auto sc_) {
-        constexpr int s = decltype(sc_)::value;
-        const int Q = S.tq[s], Pc = S.tp[s];
-        if (Q >= 0) {
+    static_for<0, Own<WAVE>::n>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value;
+      constexpr int Q = Own<WAVE>::tq(s), Pc = Own<WAVE>::tp(s);
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int a = Q * TR + 4 * v + G.g, b = Pc * TR + G.j;  // row <= column in the kept triangle
-            if (G.ok[v] && a <= b) P.cov[((size_t)slot * TRI + tri(b, a)) * N + i] = T[s][v];
-          }
-        }
-      });
-    }
+      for (int v = 0; v < 4; ++v) {
+        const int a = Q * TR + 4 * v + G.g, b = Pc * TR + G.j;  // row <= column in the kept triangle
+        if (G.ok[v] && a <= b) P.cov[((size_t)slot * TRI + tri(b, a)) * N + i] = T[s][v];
+      }
+    });
     if (tid == 0) P.diff[(size_t)slot * N + i] = diffusion;
   }
 
   // whole fixed-step solve of trajectory i
-  template <bool HELPER>
+  template <int WAVE>
   ODEF_MF_FN void run(const FilterParams& P, long i, int tid, double* __restrict__ sm) {
+    constexpr bool HELPER = WAVE == kMfHelper;
     double* m = sm + W::MV;
     double* sc = sm + W::SC;
     const size_t N = (size_t)P.N;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     Geo G;
     G.lane = tid & 63;
     G.g = G.lane >> 4;
     G.j = tid & 15;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int i = 4 * v + G.g;
-      G.ok[v] = (i < TR) && (G.j < TR);
-      G.sym[v] = (i < G.j ? i : G.j) * TR + (i < G.j ? G.j : i);
+      const int ii = 4 * v + G.g;
+      G.ok[v] = (ii < TR) && (G.j < TR);
+      G.sym[v] = (ii < G.j ? ii : G.j) * TR + (ii < G.j ? G.j : ii);
     }
-    Slots S;
-    static_for<0, NS>([&](auto sc_) {
-      constexpr int s = decltype(sc_)::value;
-      int qq = -1, pp = -1;
-      static_for<0, kMfTileWaves>([&](auto wc) {
-        constexpr int w = decltype(wc)::value;
-        constexpr int cq = make_mf_own<NT>().Q[w][s], cp = make_mf_own<NT>().P[w][s];
-        if (wave == w) {
-          qq = cq;
-          pp = cp;
-        }
-      });
-      S.tq[s] = qq;
-      S.tp[s] = pp;
-    });
-    d4 T[NS];
+    d4 T[Own<WAVE>::nreg];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) T[s] = mf::zero4();
+    for (int s = 0; s < Own<WAVE>::nreg; ++s) T[s] = mf::zero4();
     __attribute__((unused)) double pl_local[RHS::np > 0 ? RHS::np : 1];
     const double* pl = pl_local;
     for (int k = 0; k < RHS::np; ++k) pl_local[k] = P.p_shared ? P.p[k] : P.p[(size_t)k * N + i];
-    if (!HELPER && tid == 0) {  // Taylor-mode initial mean (src/state_initialization.jl), zero covariance
-      double u0[d], m0[D];
-      for (int a = 0; a < d; ++a) u0[a] = P.u0[(size_t)a * N + i];
-      taylor_init<RHS, q>(u0, pl, m0);
-      for (int k = 0; k < D; ++k) m[k] = m0[k];
-      for (int k = 0; k < 8; ++k) sc[k] = 0.0;
-      for (int a = 0; a < d; ++a) sm[W::UC + a] = u0[a];
+    if constexpr (WAVE == 0) {
+      if (tid == 0) {  // Taylor-mode initial mean (src/state_initialization.jl), zero covariance
+        double u0[d], m0[D];
+        for (int a = 0; a < d; ++a) u0[a] = P.u0[(size_t)a * N + i];
+        taylor_init<RHS, q>(u0, pl, m0);
+        for (int k = 0; k < D; ++k) m[k] = m0[k];
+        for (int k = 0; k < 8; ++k) sc[k] = 0.0;
+        for (int a = 0; a < d; ++a) sm[W::UC + a] = u0[a];
+      }
+      if (tid < 32) sm[W::Z + tid] = 0.0;  // the entries behind z[d-1] stay zero
     }
-    for (int e = tid; e < 32; e += NTHR) sm[W::Z + e] = 0.0;  // the entries behind z[d-1] stay zero
     __syncthreads();
-    if (P.everystep) save_record<HELPER>(P, i, 0, 0.0, sm, T, S, G, tid);
+    if (P.everystep) save_record<WAVE>(P, i, 0, 0.0, sm, T, G, tid);
+    if constexpr (HELPER) {
+      if (P.nsteps > 0) {
+        const double* tab0 = P.ptab + (size_t)uniform_load(P.tab_idx) * kTabStride;
+        chain_a1(P.pc, pl, tab0, sm, G.lane);
+        chain_a2(P.pc, sm, G.lane);
+        chain_b(P.pc, true, sm, fresh(G));
+        chain_c(sm, G.lane);
+      }
+    }
+    __syncthreads();
     for (long n = 0; n < P.nsteps; ++n) {
       const double* tab = P.ptab + (size_t)uniform_load(P.tab_idx + n) * kTabStride;
-      step<HELPER>(P.pc, pl, tab, P.fixed_diffusion, (int)n, sm, T, S, G, tid, wave);
-      if (P.everystep) save_record<HELPER>(P, i, n + 1, sc[4], sm, T, S, G, tid);
+      const double* tab_next = n + 1 < P.nsteps ? P.ptab + (size_t)uniform_load(P.tab_idx + n + 1) * kTabStride : nullptr;
+      step<WAVE>(P.pc, pl, tab, tab_next, P.fixed_diffusion, (int)n, sm, T, G, tid);
+      if (P.everystep) save_record<WAVE>(P, i, n + 1, sc[4], sm, T, G, tid);
     }
-    if (!P.everystep) save_record<HELPER>(P, i, 0, sc[4], sm, T, S, G, tid);
-    if (tid == 0) {
-      P.loglik[i] = sc[3];
-      P.naccept[i] = (int)P.nsteps;
-      P.nreject[i] = 0;
-      P.nf[i] = (int)P.nsteps;
-      P.njac[i] = IS_EK1 ? (int)P.nsteps : 0;
-      P.nsaved[i] = P.everystep ? (int)P.nsteps + 1 : 1;
-      bool ok = true;
-      for (int k = 0; k < D; ++k) ok = ok && (fabs(m[k]) <= 1.79769313486231570815e+308);
-      P.retcode[i] = ok ? 0 : 3;
+    if (!P.everystep) save_record<WAVE>(P, i, 0, sc[4], sm, T, G, tid);
+    if constexpr (WAVE == 0) {
+      if (tid == 0) {
+        P.loglik[i] = sc[3];
+        P.naccept[i] = (int)P.nsteps;
+        P.nreject[i] = 0;
+        P.nf[i] = (int)P.nsteps;
+        P.njac[i] = IS_EK1 ? (int)P.nsteps : 0;
+        P.nsaved[i] = P.everystep ? (int)P.nsteps + 1 : 1;
+        bool ok = true;
+        for (int k = 0; k < D; ++k) ok = ok && (fabs(m[k]) <= 1.79769313486231570815e+308);
+        P.retcode[i] = ok ? 0 : 3;
+      }
     }
   }
 #undef ODEF_MF_FN
@@ -806,10 +934,21 @@ template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kMfBlock) void ek_filter_mfma_kernel(const FilterParams P) {
   using MF = MfmaFilter<RHS, q, EK1>;
   __shared__ double sm[MF::W::size];
-  if (threadIdx.x >= 64 * kMfHelper)  // the helper wavefront: same barriers, its own code path and register allocation
-    MF::template run<true>(P, (long)blockIdx.x, (int)threadIdx.x, sm);
-  else
-    MF::template run<false>(P, (long)blockIdx.x, (int)threadIdx.x, sm);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long i = (long)blockIdx.x;
+  const int tid = (int)threadIdx.x;
+  // one code path per wavefront (see the header comment); all of them meet at the same barriers
+  switch (wave) {
+    case 0: MF::template run<0>(P, i, tid, sm); break;
+    case 1: MF::template run<1>(P, i, tid, sm); break;
+    case 2: MF::template run<2>(P, i, tid, sm); break;
+    case 3: MF::template run<3>(P, i, tid, sm); break;
+    case 4: MF::template run<4>(P, i, tid, sm); break;
+    case 5: MF::template run<5>(P, i, tid, sm); break;
+    case 6: MF::template run<6>(P, i, tid, sm); break;
+    case 7: MF::template run<7>(P, i, tid, sm); break;
+    default: MF::template run<kMfHelper>(P, i, tid, sm); break;
+  }
 }
 
 }  // namespace odef

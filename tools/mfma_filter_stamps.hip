@@ -47,11 +47,16 @@ int main() {
   hipLaunchKernelGGL((ek_filter_mfma_kernel<RhsPleiades, q, true>), dim3((unsigned)N), dim3(kMfBlock), 0, 0, P);
   CK(hipDeviceSynchronize());
   unsigned long long st[32]; CK(hipMemcpy(st, dst, sizeof st, hipMemcpyDeviceToHost));
-  const char* names[16] = {"(between steps / save)", "exchange put, P x, m^- = A m", "measure (f, J)", "z, H0, M0, W, Hs0", "congruence stage 1 (+ chol(W), sigma2 on one wavefront)",
-                           "exchange put Z", "congruence stage 2", "copies of the first-column tiles", "C0 = (A S A') H'", "(folded into the next)", "Sm = H C, factor, W = L^-1, y, loglik (helper) | + sigma2 Q",
-                           "V = C W', K = V W", "mean, T = S^- - V V'", "copies of the first-column tiles", "E = T H'", "S = T - E K', un-precondition"};
+  const char* names[16] = {"(between steps / save)", "(unused)", "(unused)", "exchange put of the tiles", "congruence stage 1 | helper: chol(H Q H') first half",
+                           "exchange put Z", "congruence stage 2 | helper: second half, sigma2", "copies of the first-column tiles", "C0 = (A S A') H'", "(unused)",
+                           "helper: Sm = H C, Cholesky, W = L^-1 | tiles: + sigma2 Q", "V = C W', K = V W | helper: y, loglik", "mean, T = S^- - V V', tile copies", "(unused)",
+                           "E = T H' | helper: next step's mean, f, J, z, H0, M0", "S = T - E K', un-precondition | helper: next W, Hs0"};
   double tot = 0; for (int k = 1; k < 16; ++k) tot += (double)st[k];
   printf("segment shares of one step (block 0 of %ld, mean over %ld steps, stamps by thread 0); %.0f cycles = %.1f us per step at 2.4 GHz\n", N, nsteps, tot / nsteps, tot / nsteps / 2400.0);
   for (int k = 1; k < 16; ++k) printf("  %-58s %6.2f %%   %8.0f cycles/step\n", names[k], 100.0 * st[k] / tot, (double)st[k] / nsteps);
+  const char* hn[11] = {"(waiting / other)", "chol(H Q H') first half", "chol(H Q H') second half", "y = L^-1 z, sigma2", "Sm blocks (24 MFMAs)", "factor_s: Cholesky of Sm, W = L^-1",
+                        "y = W z, loglik", "chain_a1: P m, A m, pairs, f, J", "chain_a2: z, H0, M0", "chain_b: W = M0 M0' (MFMA)", "chain_c: Hs0"};
+  printf("the helper wavefront's own work items (its clock):\n");
+  for (int k = 1; k < 11; ++k) printf("  %-58s %8.0f cycles/step\n", hn[k], (double)st[16 + k] / nsteps);
   return 0;
 }
