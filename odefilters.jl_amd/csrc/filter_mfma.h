@@ -26,14 +26,12 @@
 // movement; products that need the tile as the A operand (the six tiles above the diagonal of the first two derivative
 // blocks) go through a small LDS copy.  The rank-d updates read their D x d operand panels (V, K, E) from LDS.
 //
-// Code.  The tile code is instantiated once PER TILE WAVEFRONT (template parameter WAVE): which tiles a wavefront owns
-// is then a compile-time fact, every LDS address is "lane part + immediate", the source lists of the congruence are
-// exact, and a wavefront executes ~2 000 instructions per step instead of ~11 000 of a generic, run-time-indexed
-// version (whose 159 KB also overflowed the 64 KB instruction cache: the helper ran at ~80 cycles per instruction).
-// The ninth wavefront (the helper) owns no tile: it runs the two d x d factorisations -- H Q H' for sigma^2 beside the
-// congruence of the others (sigma^2 Q is added to the tiles and sigma^2 Q H' to the panel only after C0 = (A S A') H' is
-// there), Sm while everybody waits -- and, beside the tail of step n, the whole measurement chain of step n + 1 (mean
-// prediction, f, J, z, H0, M0, H Q H', the padded H0'), which depends on the mean alone.
+// Code.  Eight tile wavefronts share ONE copy of the tile code (unrolled over the <= 10 tile slots of a wavefront, the
+// tile coordinates of a slot in SGPRs); the ninth wavefront (the helper) owns no tile and has its own code path: the two
+// d x d factorisations -- H Q H' for sigma^2 beside the congruence of the others (sigma^2 Q is added to the tiles and
+// sigma^2 Q H' to the panel only after C0 = (A S A') H' is there), Sm while everybody waits -- and, beside the tail of
+// step n, the whole measurement chain of step n + 1 (mean prediction, f, J, z, H0, M0, H Q H', the padded H0'), which
+// depends on the mean alone.  The step body has to stay near the 64 KB of the instruction cache: see Slots below.
 #pragma once
 #ifndef ODEF_HOST_EMUL
 #include "ek_lane.h"
@@ -181,14 +179,21 @@ struct MfmaFilter {
   static constexpr int NT = W::NT, TR = W::TR, TSZ = W::TSZ, LDP = W::LDP, NTHR = kMfBlock;
   static constexpr int KS = (d + 3) / 4;  // k-steps of a product over the measurement index
   static_assert(make_mf_own<NT>().ok, "tile ownership table overflow");
-  // compile-time tile list of wavefront WAVE (the helper owns none)
-  template <int WAVE>
-  struct Own {
-    static constexpr int w = WAVE < kMfTileWaves ? WAVE : 0;
-    static constexpr int n = WAVE < kMfTileWaves ? make_mf_own<NT>().n[w] : 0;
-    static constexpr int tq(int s) { return make_mf_own<NT>().Q[w][s]; }
-    static constexpr int tp(int s) { return make_mf_own<NT>().P[w][s]; }
-    static constexpr int nreg = n > 0 ? n : 1;
+  static constexpr int max_load() {
+    int mx = 0;
+    for (int w = 0; w < kMfTileWaves; ++w)
+      if (make_mf_own<NT>().n[w] > mx) mx = make_mf_own<NT>().n[w];
+    return mx;
+  }
+  static constexpr int NS = max_load();  // tile slots per wavefront
+  // The tile code exists ONCE (shared by the eight tile wavefronts, unrolled over the NS slots); which tile sits in slot s
+  // of a wavefront is a wave-uniform run-time fact (SGPRs).  A per-wavefront specialisation (compile-time tile lists)
+  // executes 5x fewer instructions per wavefront but is eight instruction streams of 17 KB each: with the helper's code
+  // that is 190 KB against a 64 KB instruction cache, and measured 1.6x SLOWER.  What matters is that every per-slot
+  // address is "scalar base + lane part": the lane parts are computed once per phase, the bases on the scalar unit.
+  struct Slots {
+    int n;               // tiles of this wavefront
+    int tq[NS], tp[NS];  // tile coordinates of slot s (valid for s < n)
   };
 
   struct Geo {  // per-lane geometry of the accumulator layout
@@ -222,114 +227,144 @@ struct MfmaFilter {
 
   // ------------------------------------------------------------------------------------------------ tile phases
   // tiles -> compact exchange slots; the padding lanes of a tile store into a dummy area (no exec masking)
-  template <int WAVE>
-  ODEF_MF_FN void ex_put_all(const d4 (&T)[Own<WAVE>::nreg], const Geo& G0, double* __restrict__ ex) {
+  ODEF_MF_FN void ex_put_all(const d4 (&T)[NS], const Slots& S, const Geo& G0, double* __restrict__ ex) {
     const Geo G = fresh(G0);
-    static_for<0, Own<WAVE>::n>([&](auto sc_) {
-      constexpr int s = decltype(sc_)::value;
-      constexpr int base = uidx(Own<WAVE>::tq(s), Own<WAVE>::tp(s)) * TSZ;
+    int rel[4];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        double* p = G.ok[v] ? ex + base + (4 * v + G.g) * TR + G.j : ex + W::DUMMY + G.lane;
-        *p = T[s][v];
+    for (int v = 0; v < 4; ++v) rel[v] = G.ok[v] ? (4 * v + G.g) * TR + G.j : -1;
+    static_for<0, NS>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value;
+      if (s < S.n) {
+        const int base = uidx(S.tq[s], S.tp[s]) * TSZ;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) ex[rel[v] >= 0 ? base + rel[v] : W::DUMMY + G.lane] = T[s][v];
       }
     });
   }
 
   // first stage of predict_cov! (src/filtering.jl:33-41):  Z(Q, P) = sum_{k >= Q/2} At[Q/2][k] pj[k] pj[P/2] S(2k + Q%2, P),
   // sources in the own tile COLUMN; those below the diagonal are read transposed (S symmetric), a diagonal one through
-  // its upper triangle (the rank updates leave rounding-level asymmetry there)
-  template <int WAVE>
-  ODEF_MF_FN void stage1(d4 (&T)[Own<WAVE>::nreg], const Geo& G0, const double* __restrict__ ex, const double* __restrict__ cf1) {
+  // its upper triangle (the rank updates leave rounding-level asymmetry there).  One LDS round trip per source tile:
+  // its four values and the next coefficient.
+  ODEF_MF_FN void stage1(d4 (&T)[NS], const Slots& S, const Geo& G0, const double* __restrict__ ex, const double* __restrict__ cf1) {
     const Geo G = fresh(G0);
     const double* dir = ex + G.g * TR + G.j;
     const double* tra = ex + G.j * TR + G.g;
-    static_for<0, Own<WAVE>::n>([&](auto sc_) {
+    static_for<0, NS>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
-      constexpr int Q = Own<WAVE>::tq(s), P = Own<WAVE>::tp(s), a = Q >> 1, hq = Q & 1, b = P >> 1;
-      d4 acc = mf::zero4();
-      static_for<a, NB>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        constexpr int Qs = 2 * k + hq;
-        const double c = cf1[(a * NB + b) * NB + k];
-        if constexpr (Qs < P) {
+      if (s < S.n) {
+        const int Q = S.tq[s], P = S.tp[s], a = Q >> 1, hq = Q & 1, b = P >> 1;
+        const double* cf = cf1 + (a * NB + b) * NB;
+        d4 acc = mf::zero4();
+        double ck = cf[a];
+#pragma nounroll
+        for (int k = a; k < NB; ++k) {
+          const int Qs = 2 * k + hq;
+          const double cn = cf[k + 1 < NB ? k + 1 : k];
+          double x[4];
+          if (Qs < P) {
+            const double* src = dir + uidx(Qs, P) * TSZ;
 #pragma unroll
-          for (int v = 0; v < 4; ++v) acc[v] += c * dir[uidx(Qs, P) * TSZ + 4 * v * TR];
-        } else if constexpr (Qs == P) {
+            for (int v = 0; v < 4; ++v) x[v] = src[4 * v * TR];
+          } else if (Qs == P) {
+            const double* src = ex + uidx(Qs, P) * TSZ;
 #pragma unroll
-          for (int v = 0; v < 4; ++v) acc[v] += c * ex[uidx(Qs, P) * TSZ + G.sym[v]];
-        } else {
+            for (int v = 0; v < 4; ++v) x[v] = src[G.sym[v]];
+          } else {
+            const double* src = tra + uidx(P, Qs) * TSZ;
 #pragma unroll
-          for (int v = 0; v < 4; ++v) acc[v] += c * tra[uidx(P, Qs) * TSZ + 4 * v];
+            for (int v = 0; v < 4; ++v) x[v] = src[4 * v];
+          }
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[v] += ck * x[v];
+          ck = cn;
         }
-      });
 #pragma unroll
-      for (int v = 0; v < 4; ++v) T[s][v] = G.ok[v] ? acc[v] : 0.0;
+        for (int v = 0; v < 4; ++v) T[s][v] = G.ok[v] ? acc[v] : 0.0;
+      }
     });
   }
   // second stage:  S^-(Q, P) = sum_{k >= P/2} At[P/2][k] Z(Q, 2k + P%2)   (sigma2 Qt is added later), sources in the own tile ROW
-  template <int WAVE>
-  ODEF_MF_FN void stage2(d4 (&T)[Own<WAVE>::nreg], const Geo& G0, const double* __restrict__ ex, const double* __restrict__ cf2) {
+  ODEF_MF_FN void stage2(d4 (&T)[NS], const Slots& S, const Geo& G0, const double* __restrict__ ex, const double* __restrict__ cf2) {
     const Geo G = fresh(G0);
     const double* dir = ex + G.g * TR + G.j;
-    static_for<0, Own<WAVE>::n>([&](auto sc_) {
+    static_for<0, NS>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
-      constexpr int Q = Own<WAVE>::tq(s), P = Own<WAVE>::tp(s), b = P >> 1, hp = P & 1;
-      d4 acc = mf::zero4();
-      static_for<b, NB>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        const double c = cf2[b * NB + k];
+      if (s < S.n) {
+        const int Q = S.tq[s], P = S.tp[s], b = P >> 1, hp = P & 1;
+        const double* cf = cf2 + b * NB;
+        d4 acc = mf::zero4();
+        double ck = cf[b];
+#pragma nounroll
+        for (int k = b; k < NB; ++k) {
+          const double cn = cf[k + 1 < NB ? k + 1 : k];
+          const double* src = dir + uidx(Q, 2 * k + hp) * TSZ;
+          double x[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] += c * dir[uidx(Q, 2 * k + hp) * TSZ + 4 * v * TR];
-      });
+          for (int v = 0; v < 4; ++v) x[v] = src[4 * v * TR];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) T[s][v] = G.ok[v] ? acc[v] : 0.0;
+          for (int v = 0; v < 4; ++v) acc[v] += ck * x[v];
+          ck = cn;
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) T[s][v] = G.ok[v] ? acc[v] : 0.0;
+      }
     });
   }
   // + sigma2 Q (src/filtering.jl:35): Qt[Q/2][P/2] on the diagonal of the tiles with equal halves
-  template <int WAVE>
-  ODEF_MF_FN void add_sigma2_q(d4 (&T)[Own<WAVE>::nreg], const Geo& G0, const PriorConsts& pc, double sigma2) {
+  ODEF_MF_FN void add_sigma2_q(d4 (&T)[NS], const Slots& S, const Geo& G0, const PriorConsts& pc, double sigma2) {
     const Geo G = fresh(G0);
-    static_for<0, Own<WAVE>::n>([&](auto sc_) {
-      constexpr int s = decltype(sc_)::value;
-      constexpr int Q = Own<WAVE>::tq(s), P = Own<WAVE>::tp(s);
-      if constexpr ((Q & 1) == (P & 1)) {
-        const double sq = sigma2 * pc.Qt[Q >> 1][P >> 1];
+    bool dg[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) T[s][v] += (G.ok[v] && 4 * v + G.g == G.j) ? sq : 0.0;
+    for (int v = 0; v < 4; ++v) dg[v] = G.ok[v] && 4 * v + G.g == G.j;
+    static_for<0, NS>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value;
+      if (s < S.n) {
+        const int Q = S.tq[s], P = S.tp[s];
+        if ((Q & 1) == (P & 1)) {
+          const double sq = sigma2 * pc.Qt[Q >> 1][P >> 1];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) T[s][v] += dg[v] ? sq : 0.0;
+        }
       }
     });
   }
 
   // the ten tiles of the first four tile columns, as full 16 x 16 row-major copies: the six above the diagonal (read
   // back transposed by hproject) and the four diagonal ones (read back through their upper triangle by diag_resym)
-  template <int WAVE, bool WITH_DIAG>
-  ODEF_MF_FN void tl_put(const d4 (&T)[Own<WAVE>::nreg], const Geo& G0, double* __restrict__ tl) {
+  ODEF_MF_FN void tl_put(const d4 (&T)[NS], const Slots& S, const Geo& G0, double* __restrict__ tl, bool with_diag) {
     const Geo G = fresh(G0);
-    double* dst = tl + G.g * 16 + G.j;
-    static_for<0, Own<WAVE>::n>([&](auto sc_) {
+    double* dst0 = tl + G.g * 16 + G.j;
+    static_for<0, NS>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
-      constexpr int Q = Own<WAVE>::tq(s), P = Own<WAVE>::tp(s);
-      if constexpr (P <= 3 && (Q < P || WITH_DIAG)) {
-        constexpr int id = Q < P ? P * (P - 1) / 2 + Q : 6 + Q;
+      if (s < S.n) {
+        const int Q = S.tq[s], P = S.tp[s];
+        if (P <= 3 && (Q < P || with_diag)) {
+          double* dst = dst0 + (Q < P ? P * (P - 1) / 2 + Q : 6 + Q) * 256;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) dst[id * 256 + 64 * v] = T[s][v];
+          for (int v = 0; v < 4; ++v) dst[64 * v] = T[s][v];
+        }
       }
     });
   }
   // A diagonal tile must be EXACTLY symmetric where it enters a product as a whole (H (.) tile): its antisymmetric part
   // is not damped by the update but multiplied by (I + K H), step after step (numpy model in DESIGN.md section 3.9).
-  template <int WAVE>
-  ODEF_MF_FN void diag_resym(d4 (&T)[Own<WAVE>::nreg], const Geo& G0, const double* __restrict__ tl) {
+  ODEF_MF_FN void diag_resym(d4 (&T)[NS], const Slots& S, const Geo& G0, const double* __restrict__ tl) {
     const Geo G = fresh(G0);
-    static_for<0, Own<WAVE>::n>([&](auto sc_) {
-      constexpr int s = decltype(sc_)::value;
-      constexpr int Q = Own<WAVE>::tq(s), P = Own<WAVE>::tp(s);
-      if constexpr (Q == P && P <= 3) {
+    int so[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int i = 4 * v + G.g;
-          T[s][v] = tl[(6 + Q) * 256 + (i < G.j ? i : G.j) * 16 + (i < G.j ? G.j : i)];
+    for (int v = 0; v < 4; ++v) {
+      const int i = 4 * v + G.g;
+      so[v] = (i < G.j ? i : G.j) * 16 + (i < G.j ? G.j : i);
+    }
+    static_for<0, NS>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value;
+      if (s < S.n) {
+        const int Q = S.tq[s], P = S.tp[s];
+        if (Q == P && P <= 3) {
+          const double* src = tl + (6 + Q) * 256;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) T[s][v] = src[so[v]];
         }
       }
     });
@@ -339,8 +374,7 @@ struct MfmaFilter {
   //   block 0 (tiles Q = 0, 1):  H0-part, 8 MFMAs per tile;  block 1 (tiles 2, 3):  h1 I, one FMA per element.
   // The panel is indexed by the PLAIN measurement index a (28 real columns + 4 zero ones: 7 k-steps in the rank updates
   // instead of 8): row i of accumulator ta is a = 14 ta + i for i < 14; its two zero rows go to 28 + 2 ta + (i - 14).
-  template <int WAVE>
-  ODEF_MF_FN void hproject(const d4 (&T)[Own<WAVE>::nreg], const Geo& G0, const double* __restrict__ hs0,
+  ODEF_MF_FN void hproject(const d4 (&T)[NS], const Slots& S, const Geo& G0, const double* __restrict__ hs0,
                            const double* __restrict__ tl, double h1, double* __restrict__ out) {
     const Geo G = fresh(G0);
     const double* hp = hs0 + G.g * LDP + G.j;
@@ -353,73 +387,81 @@ struct MfmaFilter {
       ob[v] = G.j * LDP + (i < TR ? TR + i : 2 * TR + 2 + (i - TR));
     }
     d4 acc0 = mf::zero4(), acc1 = mf::zero4();
-    static_for<0, Own<WAVE>::n>([&](auto sc_) {
+    static_for<0, NS>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
-      constexpr int Q = Own<WAVE>::tq(s), P = Own<WAVE>::tp(s);
-      if constexpr (Q <= 3) {
-        if constexpr (Q <= 1) {
+      if (s < S.n) {
+        const int Q = S.tq[s], P = S.tp[s];
+        if (Q <= 3) {  // only the head of a column enters
+          if (Q <= 1) {
+            const double* h = hp + 16 * Q * LDP;
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            acc0 = mf::mfma(hp[(16 * Q + 4 * ks) * LDP], T[s][ks], acc0);
-            acc1 = mf::mfma(hp[(16 * Q + 4 * ks) * LDP + 16], T[s][ks], acc1);
+            for (int ks = 0; ks < 4; ++ks) {
+              acc0 = mf::mfma(h[4 * ks * LDP], T[s][ks], acc0);
+              acc1 = mf::mfma(h[4 * ks * LDP + 16], T[s][ks], acc1);
+            }
+          } else if (Q == 2) {
+            acc0 += h1 * T[s];
+          } else {
+            acc1 += h1 * T[s];
           }
-        } else if constexpr (Q == 2) {
-          acc0 += h1 * T[s];
-        } else {
-          acc1 += h1 * T[s];
-        }
-        if constexpr (Q == (P < 3 ? P : 3)) {  // last head tile of the column: the sources ABOVE the diagonal come transposed from the LDS copies
-          static_for<P + 1, 4>([&](auto qc) {
-            constexpr int Qc = decltype(qc)::value;
-            constexpr int id = Qc * (Qc - 1) / 2 + P;
-            if constexpr (Qc == 1) {
+          if (Q == (P < 3 ? P : 3)) {  // last head tile of the column: the sources ABOVE the diagonal come transposed from the LDS copies
+#pragma nounroll
+            for (int Qc = P + 1; Qc <= 3; ++Qc) {
+              const double* tq = tt + (Qc * (Qc - 1) / 2 + P) * 256;
+              if (Qc == 1) {
+                const double* h = hp + 16 * LDP;
 #pragma unroll
-              for (int ks = 0; ks < 4; ++ks) {
-                const double b = tt[id * 256 + 4 * ks];
-                acc0 = mf::mfma(hp[(16 * Qc + 4 * ks) * LDP], b, acc0);
-                acc1 = mf::mfma(hp[(16 * Qc + 4 * ks) * LDP + 16], b, acc1);
-              }
-            } else {
+                for (int ks = 0; ks < 4; ++ks) {
+                  const double b = tq[4 * ks];
+                  acc0 = mf::mfma(h[4 * ks * LDP], b, acc0);
+                  acc1 = mf::mfma(h[4 * ks * LDP + 16], b, acc1);
+                }
+              } else {
+                d4 x;
 #pragma unroll
-              for (int v = 0; v < 4; ++v) {
-                const double x = h1 * tt[id * 256 + 4 * v];
-                if constexpr (Qc == 2) acc0[v] += x; else acc1[v] += x;
+                for (int v = 0; v < 4; ++v) x[v] = h1 * tq[4 * v];
+                if (Qc == 2) acc0 += x; else acc1 += x;
               }
             }
-          });
+            double* o = out + 16 * P * LDP;
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            out[16 * P * LDP + oa[v]] = acc0[v];
-            out[16 * P * LDP + ob[v]] = acc1[v];
+            for (int v = 0; v < 4; ++v) {
+              o[oa[v]] = acc0[v];
+              o[ob[v]] = acc1[v];
+            }
+            acc0 = mf::zero4();
+            acc1 = mf::zero4();
           }
-          acc0 = mf::zero4();
-          acc1 = mf::zero4();
         }
       }
     });
   }
 
   // T[s] -= A_panel[tile row Q] B_panel[tile row P]'  (rank-d update of every tile), then T[s] *= scale[Q/2][P/2] if given
-  template <int WAVE, bool SCALE>
-  ODEF_MF_FN void rank_update(d4 (&T)[Own<WAVE>::nreg], const Geo& G0, const double* __restrict__ ap,
+  ODEF_MF_FN void rank_update(d4 (&T)[NS], const Slots& S, const Geo& G0, const double* __restrict__ ap,
                               const double* __restrict__ bp, const double* __restrict__ scale) {
     const Geo G = fresh(G0);
-    const double* a = ap + G.j * LDP + G.g;
-    const double* b = bp + G.j * LDP + G.g;
+    const double* a0 = ap + G.j * LDP + G.g;
+    const double* b0 = bp + G.j * LDP + G.g;
     double bf[KS];
-    static_for<0, Own<WAVE>::n>([&](auto sc_) {
+    static_for<0, NS>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value;
-      constexpr int Q = Own<WAVE>::tq(s), P = Own<WAVE>::tp(s);
-      constexpr bool reload = s == 0 || Own<WAVE>::tp(s > 0 ? s - 1 : 0) != P;
-      if constexpr (reload) {  // first tile of a run of one column: its B fragments (negated: the product is subtracted)
+      if (s < S.n) {
+        const int Q = S.tq[s], P = S.tp[s];
+        bool reload = true;
+        if constexpr (s > 0) reload = S.tp[s - 1] != P;
+        if (reload) {  // first tile of a run of one column: its B fragments (negated: the product is subtracted)
+          const double* b = b0 + 16 * P * LDP;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) bf[ks] = -b[16 * P * LDP + 4 * ks];
+          for (int ks = 0; ks < KS; ++ks) bf[ks] = -b[4 * ks];
+        }
+        const double* a = a0 + 16 * Q * LDP;
+        d4 acc = T[s];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = mf::mfma(a[4 * ks], bf[ks], acc);
+        if (scale) acc *= scale[(Q >> 1) * MAXNB + (P >> 1)];
+        T[s] = acc;
       }
-      d4 acc = T[s];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = mf::mfma(a[16 * Q * LDP + 4 * ks], bf[ks], acc);
-      if constexpr (SCALE) acc *= scale[(Q >> 1) * MAXNB + (P >> 1)];
-      T[s] = acc;
     });
   }
 
@@ -598,13 +640,12 @@ struct MfmaFilter {
   }
 
   // ---------------------------------------------------------------------------------------------------------- step
-  // One instantiation per wavefront: WAVE < kMfTileWaves for the tile wavefronts, WAVE == kMfHelper for the helper.  All
-  // instantiations execute the same sequence of barriers; none carries another's registers.
-  template <int WAVE>
+  // Compiled twice from the same source (as filter_tiles.h): HELPER = the wavefront without tiles.  Both instantiations
+  // execute the same sequence of barriers; neither carries the other's registers.
+  template <bool HELPER>
   ODEF_MF_FN void step(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab,
                        const double* __restrict__ tab_next /* null after the last step */, int fixed_diffusion, int success_iter,
-                       double* __restrict__ sm, d4 (&T)[Own<WAVE>::nreg], const Geo& G0, int tid) {
-    constexpr bool HELPER = WAVE == kMfHelper;
+                       double* __restrict__ sm, d4 (&T)[NS], const Slots& S, const Geo& G0, int tid, int wave) {
     Geo G = fresh(G0);
     double* ex = sm + W::EX;
     double* vp = sm + W::VP;
@@ -619,12 +660,12 @@ struct MfmaFilter {
     double* y = sm + W::YV;
     double* sc = sm + W::SC;
     const double h1 = tab[kTabPIJ + 1];
-    (void)m; (void)mp; (void)z; (void)y; (void)WM; (void)wl; (void)kp; (void)tl; (void)ex; (void)p; (void)success_iter; (void)tab_next;
+    (void)m; (void)mp; (void)z; (void)y; (void)WM; (void)wl; (void)kp; (void)tl; (void)ex; (void)p; (void)success_iter; (void)tab_next; (void)wave; (void)S;
 
     ODEF_MF_STAMP(0)
     // x~ = P x (src/perform_step.jl:36-38): the covariance tiles go to the exchange as they are, the scaling is folded
     // into the coefficients of the congruence.  Mean, measurement and H Q H' of this step are already there (chain_*).
-    if constexpr (!HELPER) ex_put_all<WAVE>(T, G0, ex);
+    if constexpr (!HELPER) ex_put_all(T, S, G0, ex);
     __syncthreads();
     ODEF_MF_STAMP(3)
     if constexpr (HELPER) {
@@ -646,11 +687,11 @@ struct MfmaFilter {
         ODEF_MF_HSTAMP(1)
       }
     } else {
-      stage1<WAVE>(T, G0, ex, sm + W::CF1);
+      stage1(T, S, G0, ex, sm + W::CF1);
     }
     __syncthreads();
     ODEF_MF_STAMP(4)
-    if constexpr (!HELPER) ex_put_all<WAVE>(T, G0, ex);
+    if constexpr (!HELPER) ex_put_all(T, S, G0, ex);
     __syncthreads();
     ODEF_MF_STAMP(5)
     G = fresh(G0);
@@ -680,16 +721,16 @@ struct MfmaFilter {
         ODEF_MF_HSTAMP(3)
       }
     } else {
-      stage2<WAVE>(T, G0, ex, sm + W::CF2);
+      stage2(T, S, G0, ex, sm + W::CF2);
     }
     __syncthreads();  // the exchange is dead: region R0 now holds the panels
     ODEF_MF_STAMP(6)
-    if constexpr (!HELPER) tl_put<WAVE, true>(T, G0, tl);
+    if constexpr (!HELPER) tl_put(T, S, G0, tl, true);
     __syncthreads();
     ODEF_MF_STAMP(7)
     if constexpr (!HELPER) {
-      diag_resym<WAVE>(T, G0, tl);
-      hproject<WAVE>(T, G0, hs0, tl, h1, vp);  // C0 = (A S A') H' into the V panel
+      diag_resym(T, S, G0, tl);
+      hproject(T, S, G0, hs0, tl, h1, vp);  // C0 = (A S A') H' into the V panel
     }
     __syncthreads();  // ... and sigma^2 is there
     ODEF_MF_STAMP(8)
@@ -722,7 +763,7 @@ struct MfmaFilter {
       factor_s(sm + W::SB11, sm + W::SB22, sm + W::SB21, sm + W::L21, wl, G);
       ODEF_MF_HSTAMP(5)
     } else {
-      add_sigma2_q<WAVE>(T, G0, pc, sigma2_pred);
+      add_sigma2_q(T, S, G0, pc, sigma2_pred);
     }
     __syncthreads();
     ODEF_MF_STAMP(10)
@@ -752,7 +793,7 @@ struct MfmaFilter {
       ODEF_MF_HSTAMP(6)
     } else {
       // per tile row R of the panels, one wavefront: C = C0 + sigma2 Q H', then V = C W' (in place) and K = V W
-      for (int R = WAVE; R < NT; R += kMfTileWaves) {
+      for (int R = wave; R < NT; R += kMfTileWaves) {
         {
           const int bq = R >> 1, hr = R & 1;
           const double q0 = sigma2_pred * pc.Qt[bq][0], q1 = sigma2_pred * pc.Qt[bq][1] * h1;
@@ -810,8 +851,8 @@ struct MfmaFilter {
       m[tid] = tab[kTabPIJ + tid / d] * s;
     }
     if constexpr (!HELPER) {
-      rank_update<WAVE, false>(T, G0, vp, vp, nullptr);  // bitwise symmetric on the diagonal tiles (same products, same order)
-      tl_put<WAVE, false>(T, G0, tl);                     // ... and the copies of the first-column tiles for E = T H'
+      rank_update(T, S, G0, vp, vp, nullptr);  // bitwise symmetric on the diagonal tiles (same products, same order)
+      tl_put(T, S, G0, tl, false);                     // ... and the copies of the first-column tiles for E = T H'
     }
     __syncthreads();
     ODEF_MF_STAMP(12)
@@ -820,7 +861,7 @@ struct MfmaFilter {
       if (tab_next) chain_a1(pc, p, tab_next, sm, G0.lane);  // the next step's measurement chain beside the rest of this step
       ODEF_MF_HSTAMP(7)
     } else {
-      hproject<WAVE>(T, G0, hs0, tl, h1, vp);  // E = T H' over the V panel
+      hproject(T, S, G0, hs0, tl, h1, vp);  // E = T H' over the V panel
     }
     __syncthreads();
     ODEF_MF_STAMP(14)
@@ -835,35 +876,40 @@ struct MfmaFilter {
         ODEF_MF_HSTAMP(10)
       }
     } else {
-      rank_update<WAVE, true>(T, G0, vp, kp, tab + kTabPIPI);  // S = T - E K', un-preconditioned (src/perform_step.jl:73-75)
+      rank_update(T, S, G0, vp, kp, tab + kTabPIPI);  // S = T - E K', un-preconditioned (src/perform_step.jl:73-75)
     }
     __syncthreads();
     ODEF_MF_STAMP(15)
   }
 
   // one saved record: mean, packed covariance (own tiles), diffusion
-  template <int WAVE>
+  template <bool HELPER>
   ODEF_MF_FN void save_record(const FilterParams& P, long i, long slot, double diffusion, const double* __restrict__ sm,
-                              const d4 (&T)[Own<WAVE>::nreg], const Geo& G, int tid) {
+                              const d4 (&T)[NS], const Slots& S, const Geo& G, int tid) {
     const double* m = sm + W::MV;
     const size_t N = (size_t)P.N;
     if (tid < D) P.mean[((size_t)slot * D + tid) * N + i] = m[tid];
-    static_for<0, Own<WAVE>::n>([&](auto sc_) {
-      constexpr int s = decltype(sc_)::value;
-      constexpr int Q = Own<WAVE>::tq(s), Pc = Own<WAVE>::tp(s);
+    if constexpr (!HELPER) {
+      static_for<0, NS>([&](auto sc_) {
+        constexpr int s = decltype(sc_)::value;
+        if (s < S.n) {
+          const int Q = S.tq[s], Pc = S.tp[s];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int a = Q * TR + 4 * v + G.g, b = Pc * TR + G.j;  // row <= column in the kept triangle
-        if (G.ok[v] && a <= b) P.cov[((size_t)slot * TRI + tri(b, a)) * N + i] = T[s][v];
-      }
-    });
+          for (int v = 0; v < 4; ++v) {
+            const int a = Q * TR + 4 * v + G.g, b = Pc * TR + G.j;  // row <= column in the kept triangle
+            if (G.ok[v] && a <= b) P.cov[((size_t)slot * TRI + tri(b, a)) * N + i] = T[s][v];
+          }
+        }
+      });
+    }
     if (tid == 0) P.diff[(size_t)slot * N + i] = diffusion;
   }
 
   // whole fixed-step solve of trajectory i
-  template <int WAVE>
+  template <bool HELPER>
   ODEF_MF_FN void run(const FilterParams& P, long i, int tid, double* __restrict__ sm) {
-    constexpr bool HELPER = WAVE == kMfHelper;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (HELPER) __builtin_amdgcn_s_setprio(3);  // the helper's serial work is what the others wait for: first pick at issue and instruction fetch
     double* m = sm + W::MV;
     double* sc = sm + W::SC;
     const size_t N = (size_t)P.N;
@@ -877,13 +923,30 @@ struct MfmaFilter {
       G.ok[v] = (ii < TR) && (G.j < TR);
       G.sym[v] = (ii < G.j ? ii : G.j) * TR + (ii < G.j ? G.j : ii);
     }
-    d4 T[Own<WAVE>::nreg];
+    Slots S;
+    S.n = 0;
+    static_for<0, NS>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value;
+      int qq = 0, pp = 0;
+      static_for<0, kMfTileWaves>([&](auto wc) {
+        constexpr int w = decltype(wc)::value;
+        constexpr int cq = make_mf_own<NT>().Q[w][s], cp = make_mf_own<NT>().P[w][s], cn = make_mf_own<NT>().n[w];
+        if (!HELPER && wave == w) {
+          qq = cq < 0 ? 0 : cq;
+          pp = cp < 0 ? 0 : cp;
+          S.n = cn;
+        }
+      });
+      S.tq[s] = qq;
+      S.tp[s] = pp;
+    });
+    d4 T[NS];
 #pragma unroll
-    for (int s = 0; s < Own<WAVE>::nreg; ++s) T[s] = mf::zero4();
+    for (int s = 0; s < NS; ++s) T[s] = mf::zero4();
     __attribute__((unused)) double pl_local[RHS::np > 0 ? RHS::np : 1];
     const double* pl = pl_local;
     for (int k = 0; k < RHS::np; ++k) pl_local[k] = P.p_shared ? P.p[k] : P.p[(size_t)k * N + i];
-    if constexpr (WAVE == 0) {
+    if constexpr (!HELPER) {
       if (tid == 0) {  // Taylor-mode initial mean (src/state_initialization.jl), zero covariance
         double u0[d], m0[D];
         for (int a = 0; a < d; ++a) u0[a] = P.u0[(size_t)a * N + i];
@@ -895,7 +958,7 @@ struct MfmaFilter {
       if (tid < 32) sm[W::Z + tid] = 0.0;  // the entries behind z[d-1] stay zero
     }
     __syncthreads();
-    if (P.everystep) save_record<WAVE>(P, i, 0, 0.0, sm, T, G, tid);
+    if (P.everystep) save_record<HELPER>(P, i, 0, 0.0, sm, T, S, G, tid);
     if constexpr (HELPER) {
       if (P.nsteps > 0) {
         const double* tab0 = P.ptab + (size_t)uniform_load(P.tab_idx) * kTabStride;
@@ -909,11 +972,11 @@ struct MfmaFilter {
     for (long n = 0; n < P.nsteps; ++n) {
       const double* tab = P.ptab + (size_t)uniform_load(P.tab_idx + n) * kTabStride;
       const double* tab_next = n + 1 < P.nsteps ? P.ptab + (size_t)uniform_load(P.tab_idx + n + 1) * kTabStride : nullptr;
-      step<WAVE>(P.pc, pl, tab, tab_next, P.fixed_diffusion, (int)n, sm, T, G, tid);
-      if (P.everystep) save_record<WAVE>(P, i, n + 1, sc[4], sm, T, G, tid);
+      step<HELPER>(P.pc, pl, tab, tab_next, P.fixed_diffusion, (int)n, sm, T, S, G, tid, wave);
+      if (P.everystep) save_record<HELPER>(P, i, n + 1, sc[4], sm, T, S, G, tid);
     }
-    if (!P.everystep) save_record<WAVE>(P, i, 0, sc[4], sm, T, G, tid);
-    if constexpr (WAVE == 0) {
+    if (!P.everystep) save_record<HELPER>(P, i, 0, sc[4], sm, T, S, G, tid);
+    if constexpr (!HELPER) {
       if (tid == 0) {
         P.loglik[i] = sc[3];
         P.naccept[i] = (int)P.nsteps;
@@ -934,21 +997,10 @@ template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kMfBlock) void ek_filter_mfma_kernel(const FilterParams P) {
   using MF = MfmaFilter<RHS, q, EK1>;
   __shared__ double sm[MF::W::size];
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long i = (long)blockIdx.x;
-  const int tid = (int)threadIdx.x;
-  // one code path per wavefront (see the header comment); all of them meet at the same barriers
-  switch (wave) {
-    case 0: MF::template run<0>(P, i, tid, sm); break;
-    case 1: MF::template run<1>(P, i, tid, sm); break;
-    case 2: MF::template run<2>(P, i, tid, sm); break;
-    case 3: MF::template run<3>(P, i, tid, sm); break;
-    case 4: MF::template run<4>(P, i, tid, sm); break;
-    case 5: MF::template run<5>(P, i, tid, sm); break;
-    case 6: MF::template run<6>(P, i, tid, sm); break;
-    case 7: MF::template run<7>(P, i, tid, sm); break;
-    default: MF::template run<kMfHelper>(P, i, tid, sm); break;
-  }
+  if (threadIdx.x >= 64 * kMfHelper)  // the helper wavefront: same barriers, its own code path and register allocation
+    MF::template run<true>(P, (long)blockIdx.x, (int)threadIdx.x, sm);
+  else
+    MF::template run<false>(P, (long)blockIdx.x, (int)threadIdx.x, sm);
 }
 
 }  // namespace odef
