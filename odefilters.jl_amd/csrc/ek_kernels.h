@@ -16,6 +16,9 @@
 #include "rows_filter.h"
 #include "rows_smooth.h"
 #include "smooth_mfma.h"
+#ifndef ODEF_HOST_EMUL
+#include "dense_mfma.h"
+#endif
 #include "launch.h"
 
 namespace odef {
@@ -292,6 +295,36 @@ inline bool pleiades_smooth_team() {  // ODEF_PLEIADES_SMOOTH=team: the first (v
   const char* e = getenv("ODEF_PLEIADES_SMOOTH");
   return e && e[0] == 't';
 }
+#ifndef ODEF_HOST_EMUL
+// Dense output for the workgroup-per-trajectory path (dense_mfma.h): items = (trajectory, query time), grid-strided over
+// gridDim.x workspaces of the MFMA smoother's size
+template <int d, int q>
+__global__ __launch_bounds__(kTeamBig, 2) void dense_mfma_kernel(const DenseParams P, double* ws) {
+  using W = MfmaSmoothWs<d, q + 1>;
+  __shared__ double lds[W::lds_size];
+  double* my = ws + (size_t)blockIdx.x * W::size;
+  for (size_t e = threadIdx.x; e < W::size; e += blockDim.x) my[e] = 0.0;  // padding rows / columns stay zero from here on
+  __syncthreads();
+  const long items = P.N * P.n_q;
+  for (long it = (long)blockIdx.x; it < items; it += (long)gridDim.x) {
+    dense_mfma_item<d, q>(P, it % P.N, it / P.N, my, lds);
+    __syncthreads();
+  }
+}
+constexpr long kDenseMfmaMaxGrid = 1024;
+struct LaunchTeamDense {
+  const DenseParams& P;
+  double* ws;
+  hipStream_t s;
+  template <int d, int q>
+  void operator()() {
+    const long items = P.N * P.n_q;
+    const unsigned grid = (unsigned)(items < kDenseMfmaMaxGrid ? items : kDenseMfmaMaxGrid);
+    hipLaunchKernelGGL((dense_mfma_kernel<d, q>), dim3(grid), dim3(kTeamBig), 0, s, P, ws);
+  }
+};
+#endif
+
 struct LaunchTeamSmooth {
   const SmoothParams& P;
   double* ws;

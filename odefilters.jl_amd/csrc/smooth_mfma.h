@@ -26,13 +26,14 @@ namespace odef {
 
 #ifdef ODEF_MFMA_STAMPS  // diagnostic build (tools/mfma_smooth_stamps.hip): cycles per phase of workgroup 0
 __device__ unsigned long long g_mfma_stamps[16];
+__device__ unsigned long long g_mfma_t0;
 #define ODEF_STAMP(k)                                                          \
   do {                                                                         \
     __syncthreads();                                                           \
     if (blockIdx.x == 0 && threadIdx.x == 0) {                                 \
       const unsigned long long now_ = wall_clock64();                          \
-      g_mfma_stamps[k] += now_ - stamp_t0_;                                    \
-      stamp_t0_ = now_;                                                        \
+      g_mfma_stamps[k] += now_ - g_mfma_t0;                                    \
+      g_mfma_t0 = now_;                                                        \
     }                                                                          \
   } while (0)
 #else
@@ -67,6 +68,135 @@ struct TriWalk {
     }
   }
 };
+
+// ---- the two halves of one RTS step on the workspace (shared by the smoother loop and the dense output, dense_mfma.h).
+// In:  X = P Sigma P (full symmetric, preconditioned filter covariance), mf_ = P m, SG = Sigma^s_+ (un-preconditioned, full),
+//      ms_ = m^s_+ (un-preconditioned), pj_ / pij_ = diag of P / P^-1 per state component.
+// mfma_predict_phase:  Yt = A X, mp_ = A mf_, BM = A X A' + sigma^2 Q (the predicted covariance, preconditioned),
+//                      MM = P Sigma^s_+ P - BM, dl_ = P m^s_+ - mp_
+// mfma_gain_phase:     BM = U'U, Yt <- G' = BM^-1 Yt, ms_ <- P^-1 (mf_ + G dl_), BM <- G M G'   (returns "NaN seen")
+template <int d, int q>
+__device__ inline void mfma_predict_phase(const PriorConsts& pc, double sigma2, double* __restrict__ ws, double* __restrict__ lds) {
+  using W = MfmaSmoothWs<d, q + 1>;
+  constexpr int NB = q + 1, D = W::D, DP = W::DP, DPB = W::DPB;
+  const int tid = (int)threadIdx.x, nth = (int)blockDim.x;
+  double* X = ws + W::X;
+  double* YT = ws + W::YT;
+  double* BM = ws + W::BM;
+  double* LM = ws + W::LM;
+  double* MM = ws + W::MM;
+  double* Z2 = ws + W::Z2;
+  double* SG = ws + W::SG;
+  double* mf_ = lds + W::MF;
+  double* ms_ = lds + W::MS;
+  double* mp_ = lds + W::MP;
+  double* dl_ = lds + W::DL;
+  double* pj_ = lds + W::PJ;
+  double* pij_ = lds + W::PIJ;
+  (void)X; (void)YT; (void)BM; (void)LM; (void)MM; (void)Z2; (void)SG; (void)mf_; (void)ms_; (void)mp_; (void)dl_; (void)pj_; (void)pij_; (void)DPB; (void)NB;
+  // Yt = A X (row (J, a) picks up the rows (j, a), j > J);  m^- = A m~ (src/filtering.jl:22-25)
+  // one work item = (component a, column c): the NB rows (j, a) of X in that column give all NB rows (J, a) of Yt
+  for (int e = tid; e < d * DP; e += nth) {
+    const int a = e / DP, c = e % DP;
+    double x[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) x[j] = X[(j * d + a) * DP + c];
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+      double t = x[J];
+#pragma unroll
+      for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * x[j];
+      YT[(J * d + a) * DP + c] = t;
+    }
+  }
+  for (int k = tid; k < D; k += nth) {
+    const int J = k / d, a = k % d;
+    double t = mf_[k];
+    for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * mf_[j * d + a];
+    mp_[k] = t;
+  }
+  __syncthreads();
+  ODEF_STAMP(1);  // Yt
+  // B = A X A' + sigma^2 Q (src/filtering.jl:34-35) from the rows of Yt;  M = P Sigma^s_+ P - B;  delta
+  // one work item = (row r, component b): the NB entries (k, b) of row r of Yt give all NB entries (K, b) of row r of B
+  for (int e = tid; e < D * d; e += nth) {
+    const int r = e / d, b = e % d;
+    double yv[NB], sg[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      yv[k] = YT[r * DP + k * d + b];
+      sg[k] = SG[r * DP + k * d + b];
+    }
+    const bool diag = (r % d) == b;
+    const int J = r / d;
+#pragma unroll
+    for (int K = 0; K < NB; ++K) {
+      double bv = yv[K];
+#pragma unroll
+      for (int k = K + 1; k < NB; ++k) bv += pc.At[K][k] * yv[k];
+      double qv = 0.0;
+#pragma unroll
+      for (int JJ = 0; JJ < NB; ++JJ) qv = (JJ == J) ? pc.Qt[JJ][K] : qv;
+      if (diag) bv += sigma2 * qv;
+      const int c = K * d + b;
+      BM[r * DP + c] = bv;
+      MM[r * DP + c] = sg[K] * (pj_[r] * pj_[c]) - bv;
+    }
+  }
+  // the padding block of B is the identity (R of the previous step left zeros there); M is zero there from the start
+  for (int e = tid; e < (DP - D) * DP; e += nth) {
+    const int r = D + e / DP, c = e % DP;
+    BM[r * DP + c] = (r == c) ? 1.0 : 0.0;
+    BM[c * DP + r] = (r == c) ? 1.0 : 0.0;
+  }
+  for (int k = tid; k < D; k += nth) dl_[k] = pj_[k] * ms_[k] - mp_[k];
+  __syncthreads();
+  ODEF_STAMP(2);  // B, M
+}
+template <int d, int q>
+__device__ inline bool mfma_gain_phase(double* __restrict__ ws, double* __restrict__ lds) {
+  using W = MfmaSmoothWs<d, q + 1>;
+  constexpr int NB = q + 1, D = W::D, DP = W::DP, DPB = W::DPB;
+  const int tid = (int)threadIdx.x, nth = (int)blockDim.x;
+  double* X = ws + W::X;
+  double* YT = ws + W::YT;
+  double* BM = ws + W::BM;
+  double* LM = ws + W::LM;
+  double* MM = ws + W::MM;
+  double* Z2 = ws + W::Z2;
+  double* SG = ws + W::SG;
+  double* mf_ = lds + W::MF;
+  double* ms_ = lds + W::MS;
+  double* mp_ = lds + W::MP;
+  double* dl_ = lds + W::DL;
+  double* pj_ = lds + W::PJ;
+  double* pij_ = lds + W::PIJ;
+  (void)X; (void)YT; (void)BM; (void)LM; (void)MM; (void)Z2; (void)SG; (void)mf_; (void)ms_; (void)mp_; (void)dl_; (void)pj_; (void)pij_; (void)DPB; (void)NB;
+  bool nan_seen = false;
+  // B = U'U, Gt = B^-1 Yt (the gain G = X A' (Sigma^-)^-1, src/smoothing.jl:42-43, transposed)
+  mf::wg_cholesky_upper<DPB>(BM, LM, DP, lds);
+  ODEF_STAMP(3);  // Cholesky
+  mf::wg_solve_upper<DPB>(BM, LM, YT, DP, lds);
+  ODEF_STAMP(4);  // sweeps
+  // m^s = m + G delta (src/smoothing.jl:44), un-preconditioned (:26)
+  for (int k = tid; k < D; k += nth) {
+    double t = mf_[k];
+#pragma unroll 8
+    for (int r = 0; r < D; ++r) t += YT[r * DP + k] * dl_[r];
+    const double v = t * pij_[k];
+    nan_seen = nan_seen || !(v == v);
+    ms_[k] = v;
+  }
+  // Z = M Gt, R = Z' Gt = G M G'
+  ODEF_STAMP(5);  // mean
+  mf::wg_atb<false>(MM, DP, YT, DP, DP, nullptr, Z2, DP, 0, DPB, 0, DPB);
+  __syncthreads();
+  ODEF_STAMP(6);  // Z = M Gt
+  mf::wg_atb<false>(Z2, DP, YT, DP, DP, nullptr, BM, DP, 0, DPB, 0, DPB);
+  __syncthreads();
+  ODEF_STAMP(7);  // R = Z' Gt
+  return nan_seen;
+}
 
 template <int d, int q>
 __device__ inline void smooth_mfma_traj(const SmoothParams& P, long i, double* __restrict__ ws, double* __restrict__ lds) {
@@ -113,9 +243,6 @@ __device__ inline void smooth_mfma_traj(const SmoothParams& P, long i, double* _
   }
   __syncthreads();
   bool nan_seen = false;
-#ifdef ODEF_MFMA_STAMPS
-  unsigned long long stamp_t0_ = wall_clock64();
-#endif
   for (long s = n - 2; s >= 1; --s) {
     double h;
     if (P.adaptive) h = P.tsave[(size_t)(s + 1) * N + i] - P.tsave[(size_t)s * N + i];
@@ -160,87 +287,9 @@ __device__ inline void smooth_mfma_traj(const SmoothParams& P, long i, double* _
     for (int k = tid; k < D; k += nth) mf_[k] = pj_[k] * P.mean[((size_t)s * D + k) * N + i];
     __syncthreads();
     ODEF_STAMP(0);  // unpack
-    // Yt = A X (row (J, a) picks up the rows (j, a), j > J);  m^- = A m~ (src/filtering.jl:22-25)
-    // one work item = (component a, column c): the NB rows (j, a) of X in that column give all NB rows (J, a) of Yt
-    for (int e = tid; e < d * DP; e += nth) {
-      const int a = e / DP, c = e % DP;
-      double x[NB];
-#pragma unroll
-      for (int j = 0; j < NB; ++j) x[j] = X[(j * d + a) * DP + c];
-#pragma unroll
-      for (int J = 0; J < NB; ++J) {
-        double t = x[J];
-#pragma unroll
-        for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * x[j];
-        YT[(J * d + a) * DP + c] = t;
-      }
-    }
-    for (int k = tid; k < D; k += nth) {
-      const int J = k / d, a = k % d;
-      double t = mf_[k];
-      for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * mf_[j * d + a];
-      mp_[k] = t;
-    }
-    __syncthreads();
-    ODEF_STAMP(1);  // Yt
-    // B = A X A' + sigma^2 Q (src/filtering.jl:34-35) from the rows of Yt;  M = P Sigma^s_+ P - B;  delta
-    // one work item = (row r, component b): the NB entries (k, b) of row r of Yt give all NB entries (K, b) of row r of B
-    for (int e = tid; e < D * d; e += nth) {
-      const int r = e / d, b = e % d;
-      double yv[NB], sg[NB];
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        yv[k] = YT[r * DP + k * d + b];
-        sg[k] = SG[r * DP + k * d + b];
-      }
-      const bool diag = (r % d) == b;
-      const int J = r / d;
-#pragma unroll
-      for (int K = 0; K < NB; ++K) {
-        double bv = yv[K];
-#pragma unroll
-        for (int k = K + 1; k < NB; ++k) bv += pc.At[K][k] * yv[k];
-        double qv = 0.0;
-#pragma unroll
-        for (int JJ = 0; JJ < NB; ++JJ) qv = (JJ == J) ? pc.Qt[JJ][K] : qv;
-        if (diag) bv += sigma2 * qv;
-        const int c = K * d + b;
-        BM[r * DP + c] = bv;
-        MM[r * DP + c] = sg[K] * (pj_[r] * pj_[c]) - bv;
-      }
-    }
-    // the padding block of B is the identity (R of the previous step left zeros there); M is zero there from the start
-    for (int e = tid; e < (DP - D) * DP; e += nth) {
-      const int r = D + e / DP, c = e % DP;
-      BM[r * DP + c] = (r == c) ? 1.0 : 0.0;
-      BM[c * DP + r] = (r == c) ? 1.0 : 0.0;
-    }
-    for (int k = tid; k < D; k += nth) dl_[k] = pj_[k] * ms_[k] - mp_[k];
-    __syncthreads();
-    ODEF_STAMP(2);  // B, M
-    // B = U'U, Gt = B^-1 Yt (the gain G = X A' (Sigma^-)^-1, src/smoothing.jl:42-43, transposed)
-    mf::wg_cholesky_upper<DPB>(BM, LM, DP, lds);
-    ODEF_STAMP(3);  // Cholesky
-    mf::wg_solve_upper<DPB>(BM, LM, YT, DP, lds);
-    ODEF_STAMP(4);  // sweeps
-    // m^s = m + G delta (src/smoothing.jl:44), un-preconditioned (:26)
-    for (int k = tid; k < D; k += nth) {
-      double t = mf_[k];
-#pragma unroll 8
-      for (int r = 0; r < D; ++r) t += YT[r * DP + k] * dl_[r];
-      const double v = t * pij_[k];
-      nan_seen = nan_seen || !(v == v);
-      ms_[k] = v;
-      P.smean[((size_t)s * D + k) * N + i] = v;
-    }
-    // Z = M Gt, R = Z' Gt = G M G'
-    ODEF_STAMP(5);  // mean
-    mf::wg_atb<false>(MM, DP, YT, DP, DP, nullptr, Z2, DP, 0, DPB, 0, DPB);
-    __syncthreads();
-    ODEF_STAMP(6);  // Z = M Gt
-    mf::wg_atb<false>(Z2, DP, YT, DP, DP, nullptr, BM, DP, 0, DPB, 0, DPB);
-    __syncthreads();
-    ODEF_STAMP(7);  // R = Z' Gt
+    mfma_predict_phase<d, q>(pc, sigma2, ws, lds);
+    nan_seen = mfma_gain_phase<d, q>(ws, lds) || nan_seen;
+    for (int k = tid; k < D; k += nth) P.smean[((size_t)s * D + k) * N + i] = ms_[k];
     // Sigma^s = P^-1 (X + G M G') P^-1: the record (packed lower triangle) and the carried full matrix
     {
       TriWalk tw(tid);

@@ -478,6 +478,39 @@ def test_dense_output_adaptive_common_times(pkg):
         assert np.linalg.norm(qm[i, :, :3] - truth) <= 1e-3 * np.linalg.norm(truth)
 
 
+@pytest.mark.parametrize("smooth", [False, True])
+@pytest.mark.parametrize("q", [2, 5])
+def test_dense_output_pleiades(pkg, q, smooth):
+    """sol(t) on the workgroup-per-trajectory path (state dimension 84 / 168, csrc/dense_mfma.h) against the oracle's
+    dense output (src/solution.jl:165-210): inside the grid, at a stored time, beyond the last time, before t0."""
+    vf = orc.vector_field("pleiades")
+    N, ns, dt = 3, 12, 2.0**-10
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("pleiades", vf.u0, (0.0, ns * dt), ()), perturb_scale=1e-3, n_perturbed=14)
+    sol = pkg.solve(ens, pkg.EK1(order=q, smooth=smooth), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
+    grid = sol.t
+    tq = np.array([0.3 * dt, 4.5 * dt, grid[7], 11.25 * dt, ns * dt + 0.4 * dt])
+    qm, qc = sol(tq)
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-3, n_perturbed=14)
+    consts = orc.make_consts(28, q)
+    for i in (0, 2):
+        ref = orc.solve(vf, orc.EK1(order=q, smooth=smooth), u0=u0s[i], tspan=(0.0, ns * dt), dt=dt)
+        for j, t in enumerate(tq):
+            r = orc.dense_output(ref, consts, float(t), smoothed=smooth)
+            np.testing.assert_allclose(qm[i, j, :28], r.mu[:28], rtol=1e-10, atol=1e-13, err_msg=f"traj {i} t={t}")
+            c = r.cov()
+            # compared on the scale of its largest entry -- at order 2.  At order 5 the residuals of these first steps, and
+            # with them the diffusion estimates every covariance is proportional to, are rounding noise in both implementations
+            # (entries of 1e-30, 10 % apart; the same reason test_pleiades_ensemble_parity checks no covariance at order 5):
+            # there the covariance is only required to be finite and symmetric-positive on its diagonal.
+            if q < 5:
+                assert np.abs(qc[i, j] - c).max() <= 1e-6 * np.abs(c).max() + 1e-300, (i, j)
+            else:
+                assert np.isfinite(qc[i, j]).all() and (np.diag(qc[i, j]) >= 0).all(), (i, j)
+    np.testing.assert_array_equal(qm[:, 2], (sol.x_smooth_mean() if smooth else sol.x_filt_mean())[:, 7])
+    qm2, _ = sol(np.array([-0.1]))
+    assert np.all(np.isnan(qm2))
+
+
 def test_dense_output_requires_smoothing_and_small_state(pkg):
     vf = orc.vector_field("lorenz63")
     ctx = pkg.Context("lorenz63", 3, 1, 64, smooth=True)
