@@ -521,7 +521,7 @@ struct MfmaFilter {
   // that depends on the mean alone -- m^- = A P m, u_pred, f, J, z, H0, M0, W = H Q H', the padded H0' and the
   // coefficient tables of the congruence (src/perform_step.jl:36-43,95-132, src/diffusions.jl:78).  It runs for step
   // n + 1 beside the tail of step n, so that a step of the tile wavefronts starts with the congruence right away.
-  ODEF_MF_FN void chain_a1(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab,
+  ODEF_MF_FN void chain_a1(const PriorConsts& pc, const double* __restrict__ p, const double* __restrict__ tab, bool new_table,
                            double* __restrict__ sm, int lane) {
     double* H0 = sm + W::H0;
     double* WM = sm + W::WM;
@@ -531,8 +531,10 @@ struct MfmaFilter {
     double* up = sm + W::UP;
     double* du = sm + W::DU;
     double* tabL = sm + W::TAB;  // the step's preconditioner table in LDS: per-lane indices into it below
-    for (int e = lane; e < kTabStride; e += 64) tabL[e] = tab[e];
-    tv::lds_sync();
+    if (new_table) {  // on a uniform grid the table of the previous step is already there
+      for (int e = lane; e < kTabStride; e += 64) tabL[e] = tab[e];
+      tv::lds_sync();
+    }
     for (int r = lane; r < D; r += 64) mt[r] = tabL[kTabPJ + r / d] * m[r];
     tv::lds_sync();
     const double pi0 = tabL[kTabPIJ + 0];
@@ -544,7 +546,14 @@ struct MfmaFilter {
       if (r < d) up[r] = pi0 * s;
     }
     tv::lds_sync();
-    if constexpr (HasTeamEval<RHS>::value) {
+    if constexpr (HasWaveAssemble<RHS>::value) {
+      // the vector field's own one-wavefront assembly: du, H0 = -J pi0 and M0 = H0 QL00 + I h1 QL10 in one go
+      static_assert(RHS::team_scratch <= d * W::LDd, "pair buffer must fit the W area");
+      RHS::team_eval_pairs(lane, up, WM);
+      tv::lds_sync();
+      const double h1 = tabL[kTabPIJ + 1];
+      RHS::wave_assemble_scaled(lane, up, WM, du, H0, sm + W::M0, pi0, pc.QLt[0][0], h1 * pc.QLt[1][0], IS_EK1);
+    } else if constexpr (HasTeamEval<RHS>::value) {
       static_assert(RHS::team_scratch <= d * W::LDd, "pair buffer must fit the W area");
       RHS::team_eval_pairs(lane, up, WM);
       tv::lds_sync();
@@ -570,6 +579,7 @@ struct MfmaFilter {
     const double pi0 = tabL[kTabPIJ + 0], pi1 = tabL[kTabPIJ + 1], h1 = pi1;
     if (lane < d) z[lane] = pi1 * mp[d + lane] - du[lane];
     const double ql00 = pc.QLt[0][0], dg = h1 * pc.QLt[1][0];
+    if constexpr (!HasWaveAssemble<RHS>::value)
     for (int r = lane >> 2; r < d; r += 16) {  // H0 = -J pi0 ; M0 = H0 QL00 + I h1 QL10 (src/diffusions.jl:78): row r, columns lane % 4 + 4 t
 #pragma unroll
       for (int t = 0; t < KS; ++t) {
@@ -858,7 +868,7 @@ struct MfmaFilter {
     ODEF_MF_STAMP(12)
     if constexpr (HELPER) {
       ODEF_MF_HSTAMP(0)
-      if (tab_next) chain_a1(pc, p, tab_next, sm, G0.lane);  // the next step's measurement chain beside the rest of this step
+      if (tab_next) chain_a1(pc, p, tab_next, tab_next != tab, sm, G0.lane);  // the next step's measurement chain beside the rest of this step
       ODEF_MF_HSTAMP(7)
     } else {
       hproject(T, S, G0, hs0, tl, h1, vp);  // E = T H' over the V panel
@@ -962,7 +972,7 @@ struct MfmaFilter {
     if constexpr (HELPER) {
       if (P.nsteps > 0) {
         const double* tab0 = P.ptab + (size_t)uniform_load(P.tab_idx) * kTabStride;
-        chain_a1(P.pc, pl, tab0, sm, G.lane);
+        chain_a1(P.pc, pl, tab0, true, sm, G.lane);
         chain_a2(P.pc, sm, G.lane);
         chain_b(P.pc, true, sm, fresh(G));
         chain_c(sm, G.lane);

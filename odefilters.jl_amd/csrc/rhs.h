@@ -219,6 +219,11 @@ template <class RHS, class = void>
 struct HasTeamEval { static constexpr bool value = false; };
 template <class RHS>
 struct HasTeamEval<RHS, std::enable_if_t<RHS::has_team_eval>> { static constexpr bool value = true; };
+// ... and `wave_assemble_scaled`: the assembly by one wavefront, measurement scaling included (filter_mfma.h)
+template <class RHS, class = void>
+struct HasWaveAssemble { static constexpr bool value = false; };
+template <class RHS>
+struct HasWaveAssemble<RHS, std::enable_if_t<RHS::has_wave_assemble>> { static constexpr bool value = true; };
 
 
 struct RhsFHN {  // examples/fitzhughnagumo_animation.jl:8-16, README.md:36-44
@@ -416,6 +421,68 @@ struct RhsPleiades {
           }
         }
         Jraw[e] = v;
+      }
+    }
+  }
+  // The same assembly for ONE wavefront that also applies the measurement scaling (filter_mfma.h, the helper's chain):
+  //   du as above;  H0 = -J pi0;  M0 = H0 ql00 + I dg   (src/perform_step.jl:125, src/diffusions.jl:78), both [28][28] row-major.
+  // Lane l < 56 owns half a row (row l / 2, 14 columns): the structure of J -- identity block right of the first 14 rows,
+  // the three 7 x 7 interaction blocks below, zeros elsewhere -- is decided per lane, not per entry (the generic loop
+  // above spends ~60 instructions per entry on index arithmetic; this one ~6).
+  static constexpr bool has_wave_assemble = true;
+  __device__ static void wave_assemble_scaled(int lane, const double* u, const double* pairbuf, double* du, double* H0, double* M0,
+                                              double pi0, double ql00, double dg, bool ek1) {
+    if (lane < 28) {
+      double v;
+      if (lane < 14) {
+        v = u[14 + lane];
+      } else {
+        const int i = (lane - 14) % 7;
+        const double* f = pairbuf + (lane < 21 ? 3 : 4) * 49 + i * 7;
+        v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) v += f[j];
+      }
+      du[lane] = v;
+    }
+    if (lane < 56) {
+      const int r = lane >> 1, half = lane & 1, c0 = 14 * half;
+      double jv[14];
+#pragma unroll
+      for (int k = 0; k < 14; ++k) jv[k] = 0.0;
+      if (ek1) {
+        if (r < 14) {
+          if (half == 1) {
+#pragma unroll
+            for (int k = 0; k < 14; ++k) jv[k] = (k == r) ? 1.0 : 0.0;  // J[r][r + 14] = 1
+          }
+        } else if (half == 0) {
+          const int i = (r - 14) % 7;
+          const bool yrow = r >= 21;
+          const double* ax = pairbuf + (yrow ? 1 : 0) * 49 + i * 7;  // columns 0..6:  axx (x rows) / axy (y rows)
+          const double* ay = pairbuf + (yrow ? 2 : 1) * 49 + i * 7;  // columns 7..13: axy (x rows) / ayy (y rows)
+          double sx = 0.0, sy = 0.0;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) {
+            const double a = ax[j], b = ay[j];  // the j == i entries are zero
+            jv[j] = a;
+            jv[7 + j] = b;
+            sx += a;
+            sy += b;
+          }
+#pragma unroll
+          for (int j = 0; j < 7; ++j) {
+            jv[j] = (j == i) ? -sx : jv[j];
+            jv[7 + j] = (j == i) ? -sy : jv[7 + j];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 14; ++k) {
+        const int c = c0 + k;
+        const double h0 = (0.0 - jv[k]) * pi0;
+        H0[r * 28 + c] = h0;
+        M0[r * 28 + c] = h0 * ql00 + (r == c ? dg : 0.0);
       }
     }
   }
