@@ -365,6 +365,32 @@ def test_pleiades_ensemble_parity(pkg, q, kind):
                                        f"pleiades {kind}({q}) traj {i} smoothed={smoothed}")
 
 
+@pytest.mark.parametrize("q", [1, 3, 5])
+def test_pleiades_mfma_kernel_against_tiles_kernel_nonuniform_grid(pkg, q, monkeypatch):
+    """The two D = 28 (q+1) fixed-step filters -- matrix cores / Joseph form (csrc/filter_mfma.h, default) and register tiles /
+    square-root form (csrc/filter_tiles.h) -- on a grid whose step size changes (the MFMA kernel's helper rebuilds its
+    coefficient tables and LDS preconditioner table only then), every step saved: solution block to 1e-11, all records finite,
+    same diffusions to 1e-6, same log-likelihood to 1e-6 relative."""
+    vf = orc.vector_field("pleiades")
+    N = 3
+    grid = np.concatenate([np.arange(6) * 2.0**-10, 5 * 2.0**-10 + np.arange(1, 5) * 2.0**-11, [5 * 2.0**-10 + 4 * 2.0**-11 + 2.0**-9]])
+    out = {}
+    for name, env in (("mfma", ""), ("tiles", "tiles")):
+        monkeypatch.setenv("ODEF_PLEIADES_FILTER", env)
+        ctx = pkg.Context("pleiades", q, 1, N, save_everystep=True)
+        ctx.set_problem_perturbed(vf.u0, [], 0.0, 1e-3, n_perturbed=14)
+        ctx.solve_fixed(grid)
+        assert (ctx.get(10) == 0).all()
+        out[name] = (ctx.get(0).copy(), ctx.get(1).copy(), ctx.get(2).copy(), ctx.get(4).copy())
+        ctx.close()
+    (m1, c1, d1, l1), (m0, c0, d0, l0) = out["mfma"], out["tiles"]
+    assert np.isfinite(m1).all() and np.isfinite(c1).all()
+    np.testing.assert_allclose(m1[:, :28], m0[:, :28], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(d1[2:], d0[2:], rtol=1e-6 if q < 5 else 0.2)  # order 5: the first residuals are rounding noise (see test_dense_output_pleiades)
+    if q < 5:
+        np.testing.assert_allclose(l1, l0, rtol=1e-6)
+
+
 @pytest.mark.parametrize("kind,q", [("EK1", 2), ("EK0", 3), ("EK1", 5)])
 def test_pleiades_adaptive(pkg, kind, q):
     """The reference's default solve is adaptive: PI-controlled steps on the workgroup-per-trajectory path
