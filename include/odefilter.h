@@ -192,7 +192,8 @@ int odef_smooth(odef_ctx* ctx);
 
 /* Dense output / saveat (src/solution.jl:165-210): posterior of every trajectory at the n_q host times tq
  * (smoothed != 0: the smoothed posterior, needs odef_smooth first).  Results in ODEF_F_DENSE_MEAN /
- * ODEF_F_DENSE_COV_TRIL.  Times before t0 give NaN records (the reference throws).  State dimension <= 12. */
+ * ODEF_F_DENSE_COV_TRIL.  Times before t0 give NaN records (the reference throws).  Any state dimension the solver accepts:
+ * <= 12 one lane per (trajectory, time), <= 32 one team of 16 / 32 lanes, the workgroup-per-trajectory path (168) on the MFMA smoother's algebra. */
 int odef_dense_output(odef_ctx* ctx, const double* tq, int64_t n_q, int smoothed);
 
 /* Posterior sampling on the saved grid (src/solution_sampling.jl:24-62): n_samples joint draws of the whole state

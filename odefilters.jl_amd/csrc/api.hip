@@ -675,7 +675,7 @@ int odef_dense_output(odef_ctx* c, const double* tq, int64_t n_q, int smoothed) 
   if (c->cfg.save_mode != ODEF_SAVE_EVERYSTEP) return fail(c, "odef_dense_output: needs ODEF_SAVE_EVERYSTEP");
   if (smoothed && !c->smoothed_done) return fail(c, "odef_dense_output: smoothed posterior requested but odef_smooth has not run");
   if (n_q < 1 || n_q > 65535) return fail(c, "odef_dense_output: n_q must be in 1..65535");
-  if (!c->team_path && c->D > 12) return fail(c, "odef_dense_output: built for state dimension <= 12 and for the workgroup-per-trajectory path (got %d)", c->D);
+  if (!c->team_path && c->D > 32) return fail(c, "odef_dense_output: built for state dimension <= 32 and for the workgroup-per-trajectory path (got %d)", c->D);
   if (set_device(c)) return -1;
   if (c->tq_cap < (size_t)n_q) {
     if (c->d_tq) HIPCHK(c, hipFree(c->d_tq));
@@ -709,7 +709,10 @@ int odef_dense_output(odef_ctx* c, const double* tq, int64_t n_q, int smoothed) 
   P.qmean = (double*)c->f[ODEF_F_DENSE_MEAN].ptr;
   P.qcov = (double*)c->f[ODEF_F_DENSE_COV_TRIL].ptr;
   if (c->team_path && ensure_ws(c, (size_t)dense_d28_grid(P.N * P.n_q) * team_smooth_ws_doubles(c->d, c->q))) return -1;
-  const int rc = c->jit ? (c->jit->posterior ? jit_launch(c->jit->dense, (unsigned)((P.N + 63) / 64), (unsigned)P.n_q, &P, c->stream) : -3)
+  const long rows_tpb = c->jit ? 64 / c->jit->rows_team : 1;
+  const int rc = c->jit ? (c->jit->posterior    ? jit_launch(c->jit->dense, (unsigned)((P.N + 63) / 64), (unsigned)P.n_q, &P, c->stream)
+                           : c->jit->dense_rows ? jit_launch(c->jit->dense_rows, (unsigned)((P.N * P.n_q + rows_tpb - 1) / rows_tpb), 1, &P, c->stream)
+                                                : -3)
                  : c->team_path ? launch_dense_d28(c->q, P, c->d_ws, c->stream)
                  : c->d == 2 ? launch_dense_d2(c->q, P, c->stream) : c->d == 3 ? launch_dense_d3(c->q, P, c->stream) : -3;
   if (rc) return fail(c, "odef_dense_output: no kernel for d %d order %d", c->d, c->q);

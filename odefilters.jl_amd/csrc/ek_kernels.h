@@ -16,6 +16,7 @@
 #include "rows_filter.h"
 #include "rows_smooth.h"
 #include "smooth_mfma.h"
+#include "dense_rows.h"
 #ifndef ODEF_HOST_EMUL
 #include "dense_mfma.h"
 #endif
@@ -176,6 +177,17 @@ __global__ __launch_bounds__(kWave) void dense_output_kernel(const DenseParams P
   const LaneMem xl{lds + threadIdx.x, kWave};
   if (i < P.N) dense_lane<d, q>(P, i, (long)blockIdx.y, xl);
 }
+// ... and 12 < D <= 32: one row-per-lane team per (trajectory, query time) item (dense_rows.h)
+template <int d, int q>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_num_vgpr(128))) void dense_rows_kernel(const DenseParams P) {
+  constexpr int D = d * (q + 1), TEAM = SmoothTeam<D>::lanes, TPB = kWave / TEAM;
+  using W = RowsWs<d, q + 1>;
+  __shared__ double lds[TPB * W::size];
+  const int team = threadIdx.x / TEAM, tid = threadIdx.x % TEAM;
+  const long it = (long)blockIdx.x * TPB + team;  // item = (query time, trajectory), trajectory fastest
+  RowState<D> st;
+  if (it < P.N * P.n_q) dense_rows_lane<d, q, TEAM>(P, it % P.N, it / P.N, tid, lds + team * W::size, &st);
+}
 struct LaunchDense {
   const DenseParams& P;
   hipStream_t s;
@@ -185,6 +197,10 @@ struct LaunchDense {
     if constexpr (d * (q + 1) <= kSmoothLaneMaxD) {
       dim3 grid((unsigned)((P.N + kWave - 1) / kWave), (unsigned)P.n_q);
       hipLaunchKernelGGL((dense_output_kernel<d, q>), grid, dim3(kWave), 0, s, P);
+    } else if constexpr (d * (q + 1) <= 32) {
+      constexpr int TPB = kWave / SmoothTeam<d*(q + 1)>::lanes;
+      const long items = P.N * P.n_q;
+      hipLaunchKernelGGL((dense_rows_kernel<d, q>), dim3((unsigned)((items + TPB - 1) / TPB)), dim3(kWave), 0, s, P);
     } else {
       rc = -3;
     }

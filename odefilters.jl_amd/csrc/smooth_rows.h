@@ -42,6 +42,7 @@ struct RowState {
   double csr[D];  // row r of the carried smoothed covariance (un-preconditioned)
   double pj, pij; // own preconditioner entry and its inverse
   double mf, ms;  // own component of the filter mean (preconditioned) / carried smoothed mean (un-preconditioned)
+  double mpred;   // own component of the predicted mean A m~ (preconditioned)
   double atr[MAXNB], qtr[MAXNB];  // row (r / d) of At and Qt: lane constants
 };
 
@@ -63,6 +64,180 @@ struct RowState {
   }                                                            \
   t.sync();
 #endif
+
+// ---- the two halves of one step on the team's rows (shared by the smoother loop and the dense output, dense_rows.h).
+// In (per lane r < D): L.xr = row r of P S P, L.mf = P m, L.pj / L.pij, L.csr = row r of S^s_+ (un-preconditioned), L.ms = m^s_+.
+// rows_predict_phase:  L.yr / YL = row of Y = S A', L.mpred = (A m~)_r, L.lr = row r of B = A S A' + sigma2 Q (preconditioned),
+//                      MM = row of M = P S^s_+ P - B, VDL = P m^s_+ - m^-
+// rows_gain_phase:     B = L D L', G = Y B^-1, L.ms <- P^-1 (m~ + G delta), L.csr <- full row r of P^-1 (S + G M G') P^-1
+template <int d, int q, int TEAM>
+__device__ inline void rows_predict_phase(const PriorConsts& pc, const double (&pjv)[q + 1], double sigma2, int tid, double* __restrict__ ws,
+                                          RowState<d*(q + 1)>* st) {
+  constexpr int NB = q + 1, D = d * NB;
+  using W = RowsWs<d, NB>;
+  constexpr int LD = W::LD;
+  const Team<TEAM> t{tid};
+  (void)t;
+  double* YL = ws + W::YL;
+  double* MM = ws + W::MM;
+  double* GG = ws + W::GG;
+  double* COL = ws + W::COL;
+  double* DINV = ws + W::DINV;
+  double* VMT = ws + W::VMT;
+  double* VDL = ws + W::VDL;
+  (void)YL; (void)MM; (void)GG; (void)COL; (void)DINV; (void)VMT; (void)VDL;
+  ODEF_ROWS_PHASE(
+    if (r < D) {
+_Pragma("unroll")
+      for (int K = 0; K < NB; ++K)
+_Pragma("unroll")
+        for (int b = 0; b < d; ++b) {
+          double acc = L.xr[K * d + b];
+_Pragma("unroll")
+          for (int k = K + 1; k < NB; ++k) acc += L.xr[k * d + b] * pc.At[K][k];
+          L.yr[K * d + b] = acc;
+          YL[r * LD + K * d + b] = acc;
+        }
+      VMT[r] = L.mf;
+    }
+  )
+  // phase 2: B row, M row, m^- , delta ; publish M, delta
+  ODEF_ROWS_PHASE(
+    if (r < D) {
+      const int J = r / d;
+      const int a = r % d;
+      double mp = L.mf;
+_Pragma("unroll")
+      for (int j = 0; j < NB; ++j)
+        if (j > J) mp += L.atr[j] * VMT[j * d + a];
+_Pragma("unroll")
+      for (int c = 0; c < D; ++c) {
+        double acc = L.yr[c];
+_Pragma("unroll")
+        for (int j = 0; j < NB; ++j)
+          if (j > J) acc += L.atr[j] * YL[(j * d + a) * LD + c];
+        if (a == c % d) acc += sigma2 * L.qtr[c / d];
+        L.lr[c] = acc;
+        MM[r * LD + c] = L.csr[c] * (L.pj * pjv[c / d]) - acc;  // M = P S^s_+ P - S^-
+        ODEF_SCHED_FENCE();
+      }
+      L.mpred = mp;
+      VDL[r] = L.pj * L.ms - mp;
+    }
+  )
+}
+template <int d, int q, int TEAM>
+__device__ inline void rows_gain_phase(const double (&pijv)[q + 1], int tid, double* __restrict__ ws, RowState<d*(q + 1)>* st) {
+  constexpr int NB = q + 1, D = d * NB;
+  using W = RowsWs<d, NB>;
+  constexpr int LD = W::LD;
+  const Team<TEAM> t{tid};
+  (void)t;
+  double* YL = ws + W::YL;
+  double* MM = ws + W::MM;
+  double* GG = ws + W::GG;
+  double* COL = ws + W::COL;
+  double* DINV = ws + W::DINV;
+  double* VMT = ws + W::VMT;
+  double* VDL = ws + W::VDL;
+  (void)YL; (void)MM; (void)GG; (void)COL; (void)DINV; (void)VMT; (void)VDL;
+  // phases 3..: B = L D L' (right-looking, row r in registers, column k exchanged through LDS)
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    double* col = COL + (k & 1) * D;
+    ODEF_ROWS_PHASE(
+      if (r < D && r >= k) {
+        col[r] = L.lr[k];
+        if (r == k) DINV[k] = (L.lr[k] > 0.0) ? 1.0 / L.lr[k] : 0.0;  // semi-definite rule: zero column
+      }
+    )
+    ODEF_ROWS_PHASE(
+      if (r < D && r > k) {
+        const double lik = L.lr[k] * DINV[k];
+_Pragma("unroll")
+        for (int j = k + 1; j < D; ++j)
+          if (j <= r) L.lr[j] -= lik * col[j];
+        L.lr[k] = lik;
+      }
+    )
+  }
+  // publish the unit-lower factor (Y is no longer needed in LDS; every lane keeps its Y row in registers)
+  ODEF_ROWS_PHASE(
+    if (r < D) {
+_Pragma("unroll")
+      for (int c = 0; c < D; ++c)
+        if (c < r) YL[r * LD + c] = L.lr[c];
+    }
+  )
+  // G row: g L D L' = y  ->  forward with L' (unit), scale, backward with L (unit); publish G
+  ODEF_ROWS_PHASE(
+    if (r < D) {
+_Pragma("unroll")
+      for (int k = 0; k < D; ++k) {
+        double acc = L.yr[k];
+_Pragma("unroll")
+        for (int c = 0; c < k; ++c) acc -= YL[k * LD + c] * L.yr[c];
+        L.yr[k] = acc;
+        ODEF_SCHED_FENCE();
+      }
+_Pragma("unroll")
+      for (int k = 0; k < D; ++k) L.yr[k] *= DINV[k];
+_Pragma("unroll")
+      for (int k = D - 1; k >= 0; --k) {
+        double acc = L.yr[k];
+_Pragma("unroll")
+        for (int c = k + 1; c < D; ++c) acc -= YL[c * LD + k] * L.yr[c];
+        L.yr[k] = acc;
+        ODEF_SCHED_FENCE();
+      }
+_Pragma("unroll")
+      for (int c = 0; c < D; ++c) GG[r * LD + c] = L.yr[c];
+    }
+  )
+  // mean, T = G M (row), S^s row = S + T G' ; publish the lower part for symmetrisation
+  ODEF_ROWS_PHASE(
+    if (r < D) {
+      double acc = L.mf;
+_Pragma("unroll")
+      for (int k = 0; k < D; ++k) acc += L.yr[k] * VDL[k];
+      L.ms = acc * L.pij;  // un-precondition (src/smoothing.jl:26)
+      double tr[D];
+_Pragma("unroll")
+      for (int c = 0; c < D; ++c) tr[c] = 0.0;
+_Pragma("unroll")
+      for (int k = 0; k < D; ++k) {
+_Pragma("unroll")
+        for (int c = 0; c < D; ++c) tr[c] += L.yr[k] * MM[k * LD + c];
+        ODEF_SCHED_FENCE();
+      }
+_Pragma("unroll")
+      for (int c = 0; c < D; ++c) {
+        if (c <= r) {
+          double o = L.xr[c];
+_Pragma("unroll")
+          for (int k = 0; k < D; ++k) o += tr[k] * GG[c * LD + k];
+          L.csr[c] = o * (L.pij * pijv[c / d]);
+        }
+        ODEF_SCHED_FENCE();
+      }
+    }
+  )
+  // the M buffer is free now: exchange the lower triangle so that every lane holds its full (symmetric) row
+  ODEF_ROWS_PHASE(
+    if (r < D) {
+_Pragma("unroll")
+      for (int c = 0; c < D; ++c)
+        if (c <= r) MM[r * LD + c] = L.csr[c];
+    }
+  )
+  ODEF_ROWS_PHASE(
+    if (r < D) {
+_Pragma("unroll")
+      for (int c = 0; c < D; ++c)
+        if (c > r) L.csr[c] = MM[c * LD + r];
+    }
+  )
+}
 
 // whole backward pass of trajectory i.  `st`: one RowState (device) / TEAM RowStates (host emulation).
 template <int d, int q, int TEAM>
@@ -146,7 +321,7 @@ _Pragma("unroll")
       continue;
     }
     const double sigma2 = P.diff[(size_t)(s + 1) * N + i];
-    // phase 1: load row r, precondition, Y row (own row only), publish Y and m~
+    // phase 1: load row r and precondition it
     ODEF_ROWS_PHASE(
       if (r < D) {
         double pj_r = pjv[0];
@@ -161,136 +336,12 @@ _Pragma("unroll")
         L.mf = pj_r * P.mean[((size_t)s * D + r) * N + i];
 _Pragma("unroll")
         for (int c = 0; c < D; ++c) L.xr[c] = P.cov[((size_t)s * TRI + symidx(r, c)) * N + i] * (pj_r * pjv[c / d]);
-_Pragma("unroll")
-        for (int K = 0; K < NB; ++K)
-_Pragma("unroll")
-          for (int b = 0; b < d; ++b) {
-            double acc = L.xr[K * d + b];
-_Pragma("unroll")
-            for (int k = K + 1; k < NB; ++k) acc += L.xr[k * d + b] * pc.At[K][k];
-            L.yr[K * d + b] = acc;
-            YL[r * LD + K * d + b] = acc;
-          }
-        VMT[r] = L.mf;
       }
     )
-    // phase 2: B row, M row, m^- , delta ; publish M, delta
+    rows_predict_phase<d, q, TEAM>(pc, pjv, sigma2, tid, ws, st);
+    rows_gain_phase<d, q, TEAM>(pijv, tid, ws, st);
     ODEF_ROWS_PHASE(
       if (r < D) {
-        const int J = r / d;
-        const int a = r % d;
-        double mp = L.mf;
-_Pragma("unroll")
-        for (int j = 0; j < NB; ++j)
-          if (j > J) mp += L.atr[j] * VMT[j * d + a];
-_Pragma("unroll")
-        for (int c = 0; c < D; ++c) {
-          double acc = L.yr[c];
-_Pragma("unroll")
-          for (int j = 0; j < NB; ++j)
-            if (j > J) acc += L.atr[j] * YL[(j * d + a) * LD + c];
-          if (a == c % d) acc += sigma2 * L.qtr[c / d];
-          L.lr[c] = acc;
-          MM[r * LD + c] = L.csr[c] * (L.pj * pjv[c / d]) - acc;  // M = P S^s_+ P - S^-
-          ODEF_SCHED_FENCE();
-        }
-        VDL[r] = L.pj * L.ms - mp;
-      }
-    )
-    // phases 3..: B = L D L' (right-looking, row r in registers, column k exchanged through LDS)
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      double* col = COL + (k & 1) * D;
-      ODEF_ROWS_PHASE(
-        if (r < D && r >= k) {
-          col[r] = L.lr[k];
-          if (r == k) DINV[k] = (L.lr[k] > 0.0) ? 1.0 / L.lr[k] : 0.0;  // semi-definite rule: zero column
-        }
-      )
-      ODEF_ROWS_PHASE(
-        if (r < D && r > k) {
-          const double lik = L.lr[k] * DINV[k];
-_Pragma("unroll")
-          for (int j = k + 1; j < D; ++j)
-            if (j <= r) L.lr[j] -= lik * col[j];
-          L.lr[k] = lik;
-        }
-      )
-    }
-    // publish the unit-lower factor (Y is no longer needed in LDS; every lane keeps its Y row in registers)
-    ODEF_ROWS_PHASE(
-      if (r < D) {
-_Pragma("unroll")
-        for (int c = 0; c < D; ++c)
-          if (c < r) YL[r * LD + c] = L.lr[c];
-      }
-    )
-    // G row: g L D L' = y  ->  forward with L' (unit), scale, backward with L (unit); publish G
-    ODEF_ROWS_PHASE(
-      if (r < D) {
-_Pragma("unroll")
-        for (int k = 0; k < D; ++k) {
-          double acc = L.yr[k];
-_Pragma("unroll")
-          for (int c = 0; c < k; ++c) acc -= YL[k * LD + c] * L.yr[c];
-          L.yr[k] = acc;
-          ODEF_SCHED_FENCE();
-        }
-_Pragma("unroll")
-        for (int k = 0; k < D; ++k) L.yr[k] *= DINV[k];
-_Pragma("unroll")
-        for (int k = D - 1; k >= 0; --k) {
-          double acc = L.yr[k];
-_Pragma("unroll")
-          for (int c = k + 1; c < D; ++c) acc -= YL[c * LD + k] * L.yr[c];
-          L.yr[k] = acc;
-          ODEF_SCHED_FENCE();
-        }
-_Pragma("unroll")
-        for (int c = 0; c < D; ++c) GG[r * LD + c] = L.yr[c];
-      }
-    )
-    // mean, T = G M (row), S^s row = S + T G' ; publish the lower part for symmetrisation
-    ODEF_ROWS_PHASE(
-      if (r < D) {
-        double acc = L.mf;
-_Pragma("unroll")
-        for (int k = 0; k < D; ++k) acc += L.yr[k] * VDL[k];
-        L.ms = acc * L.pij;  // un-precondition (src/smoothing.jl:26)
-        double tr[D];
-_Pragma("unroll")
-        for (int c = 0; c < D; ++c) tr[c] = 0.0;
-_Pragma("unroll")
-        for (int k = 0; k < D; ++k) {
-_Pragma("unroll")
-          for (int c = 0; c < D; ++c) tr[c] += L.yr[k] * MM[k * LD + c];
-          ODEF_SCHED_FENCE();
-        }
-_Pragma("unroll")
-        for (int c = 0; c < D; ++c) {
-          if (c <= r) {
-            double o = L.xr[c];
-_Pragma("unroll")
-            for (int k = 0; k < D; ++k) o += tr[k] * GG[c * LD + k];
-            L.csr[c] = o * (L.pij * pijv[c / d]);
-          }
-          ODEF_SCHED_FENCE();
-        }
-      }
-    )
-    // the M buffer is free now: exchange the lower triangle so that every lane holds its full (symmetric) row
-    ODEF_ROWS_PHASE(
-      if (r < D) {
-_Pragma("unroll")
-        for (int c = 0; c < D; ++c)
-          if (c <= r) MM[r * LD + c] = L.csr[c];
-      }
-    )
-    ODEF_ROWS_PHASE(
-      if (r < D) {
-_Pragma("unroll")
-        for (int c = 0; c < D; ++c)
-          if (c > r) L.csr[c] = MM[c * LD + r];
         nan_seen = nan_seen || !(L.ms == L.ms);
         P.smean[((size_t)s * D + r) * N + i] = L.ms;
 _Pragma("unroll")

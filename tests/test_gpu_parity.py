@@ -537,7 +537,7 @@ def test_dense_output_pleiades(pkg, q, smooth):
     assert np.all(np.isnan(qm2))
 
 
-def test_dense_output_requires_smoothing_and_small_state(pkg):
+def test_dense_output_requires_smoothing(pkg):
     vf = orc.vector_field("lorenz63")
     ctx = pkg.Context("lorenz63", 3, 1, 64, smooth=True)
     ctx.set_problem_perturbed(vf.u0, vf.p, 0.0, 1e-2)
@@ -545,12 +545,32 @@ def test_dense_output_requires_smoothing_and_small_state(pkg):
     with pytest.raises(pkg.OdefError, match="odef_smooth has not run"):
         ctx.dense_output([0.001], True)
     ctx.close()
-    ctx = pkg.Context("lorenz63", 5, 1, 64, smooth=False)
-    ctx.set_problem_perturbed(vf.u0, vf.p, 0.0, 1e-2)
-    ctx.solve_fixed(np.arange(9) * 2.0**-9)
-    with pytest.raises(pkg.OdefError, match="state dimension <= 12"):
-        ctx.dense_output([0.001], False)
-    ctx.close()
+
+
+@pytest.mark.parametrize("smooth", [False, True])
+@pytest.mark.parametrize("q", [4, 5])
+def test_dense_output_row_teams(pkg, q, smooth):
+    """sol(t) for 12 < state dimension <= 32 (Lorenz-63 at orders 4 and 5: D = 15 on teams of 16 lanes, D = 18 on teams of 32;
+    csrc/dense_rows.h) against the oracle's dense output: inside the grid, at a stored time, beyond the last time, before t0."""
+    vf = orc.vector_field("lorenz63")
+    N, dt, t1 = 9, 2.0**-6, 0.25
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, (0.0, t1), vf.p), perturb_scale=1e-2)
+    sol = pkg.solve(ens, pkg.EK1(order=q, smooth=smooth), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
+    grid = sol.t
+    tq = np.concatenate([np.linspace(0.0, t1, 9) + 0.3 * dt, [grid[3], t1 + 0.01]])
+    qm, qc = sol(tq)
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    consts = orc.make_consts(3, q)
+    for i in (0, 8):
+        ref = orc.solve(vf, orc.EK1(order=q, smooth=smooth), u0=u0s[i], tspan=(0.0, t1), dt=dt)
+        for j, t in enumerate(tq):
+            r = orc.dense_output(ref, consts, float(t), smoothed=smooth)
+            np.testing.assert_allclose(qm[i, j, :3], r.mu[:3], rtol=1e-9, atol=1e-12, err_msg=f"traj {i} t={t}")
+            c = r.cov()
+            assert np.abs(qc[i, j] - c).max() <= 1e-5 * np.abs(c).max() + 1e-300, (i, j)
+    np.testing.assert_array_equal(qm[:, 9], (sol.x_smooth_mean() if smooth else sol.x_filt_mean())[:, 3])
+    qm2, _ = sol(np.array([-0.1]))
+    assert np.all(np.isnan(qm2))
 
 
 # ---- posterior sampling -----------------------------------------------------------------------------------
@@ -772,8 +792,8 @@ struct {name} {{
 
 @pytest.mark.parametrize("d,q", [(5, 2), (8, 1)])
 def test_user_vector_field_larger_state(pkg, d, q):
-    """Lorenz-96 with d variables, D = d(q+1) = 15 / 16: the lane filter plus the row-team smoother, both run-time
-    compiled; EK1 with the forward-mode Jacobian."""
+    """Lorenz-96 with d variables, D = d(q+1) = 15 / 16: the lane filter plus the row-team smoother and dense output, all
+    run-time compiled; EK1 with the forward-mode Jacobian."""
     name = f"UserL96d{d}"
     pkg.compile_rhs(name, _l96_source(name, d), d, 1)
 
@@ -799,8 +819,14 @@ def test_user_vector_field_larger_state(pkg, d, q):
     np.testing.assert_allclose(sol.x_filt_mean()[0][:, :d], ref.means(smoothed=False)[:, :d], rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(sol.u[0], ref.u, rtol=1e-9, atol=1e-13)
     assert P.cov_err(sol.x_smooth_cov()[0], ref.covs(smoothed=True)) < 1e-5
-    with pytest.raises(pkg.OdefError, match="state dimension <= 12"):
-        sol(np.array([0.1]))
+    # sol(t) on the run-time compiled row-team dense kernel (csrc/dense_rows.h), smoothed posterior
+    tq = np.array([0.013, 0.1, 2.0**-7 * 5, 0.2 + 0.004])
+    qm, qc = sol(tq)
+    consts = orc.make_consts(d, q)
+    for j, t in enumerate(tq):
+        r = orc.dense_output(ref, consts, float(t), smoothed=True)
+        np.testing.assert_allclose(qm[0, j, :d], r.mu[:d], rtol=1e-9, atol=1e-12)
+        assert np.abs(qc[0, j] - r.cov()).max() <= 1e-5 * np.abs(r.cov()).max() + 1e-300
 
 
 def test_user_vector_field_without_jacobian_uses_forward_mode(pkg):
