@@ -17,6 +17,7 @@
 #include "rows_smooth.h"
 #include "smooth_mfma.h"
 #include "dense_rows.h"
+#include "sample_rows.h"
 #ifndef ODEF_HOST_EMUL
 #include "dense_mfma.h"
 #endif
@@ -218,6 +219,17 @@ __global__ __launch_bounds__(kWave) void sample_kernel(const SampleParams P) {
   const long n_hi = (P.adaptive && !P.tq) ? wave_uniform_max(valid ? (long)P.nsaved[i] : 0, valid) : P.n_save;
   if (valid) sample_lane<d, q>(P, i, (long)blockIdx.y, xl, n_hi);
 }
+// ... and 12 < D <= 32: one row-per-lane team per (trajectory, sample) item (sample_rows.h)
+template <int d, int q>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_num_vgpr(128))) void sample_rows_kernel(const SampleParams P) {
+  constexpr int D = d * (q + 1), TEAM = SmoothTeam<D>::lanes, TPB = kWave / TEAM;
+  using W = RowsWs<d, q + 1>;
+  __shared__ double lds[TPB * W::size];
+  const int team = threadIdx.x / TEAM, tid = threadIdx.x % TEAM;
+  const long it = (long)blockIdx.x * TPB + team;  // item = (sample, trajectory), trajectory fastest
+  RowState<D> st;
+  if (it < P.N * P.n_samples) sample_rows_lane<d, q, TEAM>(P, it % P.N, it / P.N, tid, lds + team * W::size, &st);
+}
 struct LaunchSample {
   const SampleParams& P;
   hipStream_t s;
@@ -227,6 +239,10 @@ struct LaunchSample {
     if constexpr (d * (q + 1) <= kSmoothLaneMaxD) {
       const dim3 grid((unsigned)((P.N + kWave - 1) / kWave), (unsigned)P.n_samples);
       hipLaunchKernelGGL((sample_kernel<d, q>), grid, dim3(kWave), 0, s, P);
+    } else if constexpr (d * (q + 1) <= 32) {
+      constexpr int TPB = kWave / SmoothTeam<d*(q + 1)>::lanes;
+      const long items = P.N * P.n_samples;
+      hipLaunchKernelGGL((sample_rows_kernel<d, q>), dim3((unsigned)((items + TPB - 1) / TPB)), dim3(kWave), 0, s, P);
     } else {
       rc = -3;
     }

@@ -14,6 +14,7 @@ struct JitModule {
   hipFunction_t smooth_fixed = nullptr, smooth_adapt = nullptr, dense = nullptr, sample = nullptr;
   hipFunction_t smooth_rows = nullptr;  // 12 < state dimension <= 32: row-per-lane team smoother
   hipFunction_t dense_rows = nullptr;   // ... and dense output on the same teams (one team per (trajectory, query time))
+  hipFunction_t sample_rows = nullptr;  // ... and posterior sampling (one team per (trajectory, sample))
   int rows_team = 16;                   // lanes per trajectory of that kernel
   bool posterior = false;  // lane smoother / dense output / sampler available (state dimension <= 12)
 };

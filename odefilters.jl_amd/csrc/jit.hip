@@ -56,7 +56,7 @@ std::string translation_unit(const JitRhs& r, int q, int ek1, bool with_posterio
   s += "#include \"ek_lane.h\"\n";
   if (with_posterior_kernels) s += "#include \"smooth_lane.h\"\n#include \"dense_lane.h\"\n#include \"sample_lane.h\"\n";
   const bool rows_smoother = !with_posterior_kernels && D <= 32;  // 12 < D <= 32: the row-per-lane team smoother
-  if (rows_smoother) s += "#include \"smooth_rows.h\"\n#include \"dense_rows.h\"\n";
+  if (rows_smoother) s += "#include \"smooth_rows.h\"\n#include \"dense_rows.h\"\n#include \"sample_rows.h\"\n";
   s += "namespace odef {\n";
   s += r.source;
   s += "\nusing RhsJit = " + r.name + ";\n";
@@ -116,6 +116,14 @@ std::string translation_unit(const JitRhs& r, int q, int ek1, bool with_posterio
          "  const long it = (long)blockIdx.x * TPB + team;\n"
          "  RowState<" + DD + " * (" + Q + " + 1)> st;\n"
          "  if (it < P.N * P.n_q) dense_rows_lane<" + DD + ", " + Q + ", TEAM>(P, it % P.N, it / P.N, tid, lds + team * W::size, &st);\n}\n";
+    s += "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void odef_jit_sample_rows(const SampleParams P) {\n"
+         "  constexpr int TEAM = " + TEAM + ", TPB = 64 / TEAM;\n"
+         "  using W = RowsWs<" + DD + ", " + Q + " + 1>;\n"
+         "  __shared__ double lds[TPB * W::size];\n"
+         "  const int team = threadIdx.x / TEAM, tid = threadIdx.x % TEAM;\n"
+         "  const long it = (long)blockIdx.x * TPB + team;\n"
+         "  RowState<" + DD + " * (" + Q + " + 1)> st;\n"
+         "  if (it < P.N * P.n_samples) sample_rows_lane<" + DD + ", " + Q + ", TEAM>(P, it % P.N, it / P.N, tid, lds + team * W::size, &st);\n}\n";
   }
   s += "}  // namespace odef\n";
   return s;
@@ -266,7 +274,8 @@ JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& e
       {&m->smooth_adapt, "odef_jit_smooth_adapt", m->posterior}, {&m->dense, "odef_jit_dense", m->posterior},
       {&m->sample, "odef_jit_sample", m->posterior},
       {&m->smooth_rows, "odef_jit_smooth_rows", !m->posterior && r.d * (q + 1) <= 32},
-      {&m->dense_rows, "odef_jit_dense_rows", !m->posterior && r.d * (q + 1) <= 32}};
+      {&m->dense_rows, "odef_jit_dense_rows", !m->posterior && r.d * (q + 1) <= 32},
+      {&m->sample_rows, "odef_jit_sample_rows", !m->posterior && r.d * (q + 1) <= 32}};
   for (auto& e : fn) {
     if (!e.need) continue;
     if (hipModuleGetFunction(e.f, m->mod, e.name) != hipSuccess) {

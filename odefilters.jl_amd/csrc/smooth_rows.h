@@ -65,6 +65,34 @@ struct RowState {
   t.sync();
 #endif
 
+// L D L' of the symmetric matrix whose row r sits in L.lr (columns <= r referenced), right-looking, column k exchanged through
+// LDS (COL: 2 x D, DINV: D).  Afterwards L.lr[c], c < r, is the unit-lower factor, L.lr[r] the pivot D_r, DINV[k] = 1 / D_k
+// (semi-definite rule: 0 for a non-positive pivot, which zeroes its column).
+template <int D, int TEAM>
+__device__ inline void rows_ldl(int tid, double* __restrict__ COL, double* __restrict__ DINV, RowState<D>* st) {
+  const Team<TEAM> t{tid};
+  (void)t;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    double* col = COL + (k & 1) * D;
+    ODEF_ROWS_PHASE(
+      if (r < D && r >= k) {
+        col[r] = L.lr[k];
+        if (r == k) DINV[k] = (L.lr[k] > 0.0) ? 1.0 / L.lr[k] : 0.0;  // semi-definite rule: zero column
+      }
+    )
+    ODEF_ROWS_PHASE(
+      if (r < D && r > k) {
+        const double lik = L.lr[k] * DINV[k];
+_Pragma("unroll")
+        for (int j = k + 1; j < D; ++j)
+          if (j <= r) L.lr[j] -= lik * col[j];
+        L.lr[k] = lik;
+      }
+    )
+  }
+}
+
 // ---- the two halves of one step on the team's rows (shared by the smoother loop and the dense output, dense_rows.h).
 // In (per lane r < D): L.xr = row r of P S P, L.mf = P m, L.pj / L.pij, L.csr = row r of S^s_+ (un-preconditioned), L.ms = m^s_+.
 // rows_predict_phase:  L.yr / YL = row of Y = S A', L.mpred = (A m~)_r, L.lr = row r of B = A S A' + sigma2 Q (preconditioned),
@@ -141,26 +169,7 @@ __device__ inline void rows_gain_phase(const double (&pijv)[q + 1], int tid, dou
   double* VMT = ws + W::VMT;
   double* VDL = ws + W::VDL;
   (void)YL; (void)MM; (void)GG; (void)COL; (void)DINV; (void)VMT; (void)VDL;
-  // phases 3..: B = L D L' (right-looking, row r in registers, column k exchanged through LDS)
-#pragma unroll
-  for (int k = 0; k < D; ++k) {
-    double* col = COL + (k & 1) * D;
-    ODEF_ROWS_PHASE(
-      if (r < D && r >= k) {
-        col[r] = L.lr[k];
-        if (r == k) DINV[k] = (L.lr[k] > 0.0) ? 1.0 / L.lr[k] : 0.0;  // semi-definite rule: zero column
-      }
-    )
-    ODEF_ROWS_PHASE(
-      if (r < D && r > k) {
-        const double lik = L.lr[k] * DINV[k];
-_Pragma("unroll")
-        for (int j = k + 1; j < D; ++j)
-          if (j <= r) L.lr[j] -= lik * col[j];
-        L.lr[k] = lik;
-      }
-    )
-  }
+  rows_ldl<D, TEAM>(tid, COL, DINV, st);
   // publish the unit-lower factor (Y is no longer needed in LDS; every lane keeps its Y row in registers)
   ODEF_ROWS_PHASE(
     if (r < D) {

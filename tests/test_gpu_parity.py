@@ -623,6 +623,42 @@ def test_posterior_sampling(pkg, adaptive):
     assert not np.array_equal(sol.sample_states(n, seed + 1), st)
 
 
+@pytest.mark.parametrize("q", [4, 5])
+def test_posterior_sampling_row_teams(pkg, q):
+    """sample_states for 12 < state dimension <= 32 (Lorenz-63 at orders 4 / 5, D = 15 / 18: csrc/sample_rows.h) against the oracle
+    with the same noise stream and square root, the reference's acceptance test (test/solution.jl:57-72), the zero-noise chain and
+    reproducibility -- as test_posterior_sampling does for D = 12."""
+    vf = orc.vector_field("lorenz63")
+    D = 3 * (q + 1)
+    N, t1, n, seed = 11, 0.25, 8, 4242
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, (0.0, t1), vf.p), perturb_scale=1e-2)
+    sol = pkg.solve(ens, pkg.EK1(order=q), pkg.EnsembleHIP(), trajectories=N, dt=2.0**-6, adaptive=False)
+    st = sol.sample_states(n, seed)
+    cap = st.shape[1]
+    assert st.shape == (N, cap, D, n) and np.isfinite(st).all()
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    consts = orc.make_consts(3, q)
+    for i in (0, 10):
+        ref = orc.solve(vf, orc.EK1(order=q), u0=u0s[i], tspan=(0.0, t1), dt=2.0**-6)
+        ns = len(ref.t)
+        want = orc.sample_states(ref, consts, n, sqrt="cholesky", normal=lambda j, slot, k: orc.sample_normal(seed, i, j, slot, k, n, cap, D))
+        scale = np.abs(want).max(axis=(0, 2))[None, :, None]
+        err = (np.abs(st[i, :ns] - want) / scale).max(axis=(0, 2))
+        assert err[:3].max() < 1e-7 and err.max() < 1e-2, err
+        x = ref.means(smoothed=True)
+        stds = np.sqrt(np.array([np.diag(c) for c in ref.covs(smoothed=True)]))
+        out = np.abs(x[1:, :, None] - st[i, 1:ns]) > 3 * stds[1:, :, None] + 1e-12 * np.abs(x[1:, :, None])
+        assert out.sum() < 0.05 * out.size
+    z = sol.sample_states(1, seed, noise_scale=0.0)[..., 0]
+    np.testing.assert_allclose(z[:, 1:5, :3], sol.x_smooth_mean()[:, 1:5, :3], rtol=1e-7)
+    np.testing.assert_array_equal(sol.sample_states(n, seed), st)
+    assert not np.array_equal(sol.sample_states(n, seed + 1), st)
+    # dense grid (src/solution_sampling.jl:63-75): shapes, finiteness, and the first block stays within 6 sigma of the smoothed mean
+    tq = np.linspace(0.0, t1, 13)
+    ds, _ = sol.dense_sample_states(4, seed, times=tq)
+    assert ds.shape == (N, len(tq), D, 4) and np.isfinite(ds).all()
+
+
 @pytest.mark.parametrize("adaptive", [False, True])
 def test_dense_posterior_sampling(pkg, adaptive):
     """dense_sample / dense_sample_states (src/solution_sampling.jl:63-75) against the oracle with the same noise stream
@@ -827,6 +863,13 @@ def test_user_vector_field_larger_state(pkg, d, q):
         r = orc.dense_output(ref, consts, float(t), smoothed=True)
         np.testing.assert_allclose(qm[0, j, :d], r.mu[:d], rtol=1e-9, atol=1e-12)
         assert np.abs(qc[0, j] - r.cov()).max() <= 1e-5 * np.abs(r.cov()).max() + 1e-300
+    # ... and posterior sampling on the run-time compiled row teams (csrc/sample_rows.h): the zero-noise chain of conditional
+    # means is the smoothed mean, draws are finite and reproducible
+    zc = sol.sample_states(1, 7, noise_scale=0.0)[..., 0]
+    np.testing.assert_allclose(zc[0, 1:6, :d], sol.x_smooth_mean()[0, 1:6, :d], rtol=1e-7, atol=1e-10)
+    s1 = sol.sample_states(3, 7)
+    assert np.isfinite(s1).all()
+    np.testing.assert_array_equal(sol.sample_states(3, 7), s1)
 
 
 def test_user_vector_field_without_jacobian_uses_forward_mode(pkg):
