@@ -201,15 +201,15 @@ int odef_dense_output(odef_ctx* ctx, const double* tq, int64_t n_q, int smoothed
  * ODEF_SAVE_EVERYSTEP (the reference asserts a smoothing solve, :16); odef_smooth itself is not required.
  * The N(0,1) stream is counter-based and reproducible from `seed` (splitmix64 + Box-Muller, see
  * oracle/odefilter_oracle.py sample_normal); noise_scale = 1 gives samples, 0 the chain of conditional means.
- * Result in ODEF_F_SAMPLES; sample(sol, n) of the reference is its rows 0..d-1.  State dimension <= 32 (not the
- * workgroup-per-trajectory path). */
+ * Result in ODEF_F_SAMPLES; sample(sol, n) of the reference is its rows 0..d-1.  Any state dimension the solver accepts
+ * (<= 12 one lane per (trajectory, sample), <= 32 one team of 16 / 32 lanes, the workgroup-per-trajectory path on the MFMA algebra). */
 int odef_sample(odef_ctx* ctx, int64_t n_samples, uint64_t seed, double noise_scale);
 
 /* Posterior sampling on a dense grid (dense_sample_states / dense_sample, src/solution_sampling.jl:63-75): the FILTER
  * posterior is interpolated at the n_q host times tq (as odef_dense_output with smoothed = 0; the reference uses
  * range(t0, t_end, length = 1000)) and the backward sampler of odef_sample runs over those states, the diffusion
  * of an interval looked up by time (:41).  Overwrites ODEF_F_DENSE_MEAN / ODEF_F_DENSE_COV_TRIL; result in
- * ODEF_F_SAMPLES as [n_q][D][n_samples][N].  tq must be non-decreasing and >= t0.  State dimension <= 32. */
+ * ODEF_F_SAMPLES as [n_q][D][n_samples][N].  tq must be non-decreasing and >= t0.  Any state dimension the solver accepts. */
 int odef_dense_sample(odef_ctx* ctx, const double* tq, int64_t n_q, int64_t n_samples, uint64_t seed, double noise_scale);
 
 int64_t odef_n_save(const odef_ctx* ctx); /* leading dimension of MEAN/COV_TRIL/DIFFUSION/T */

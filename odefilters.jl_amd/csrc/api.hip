@@ -726,7 +726,7 @@ int odef_sample(odef_ctx* c, int64_t n_samples, uint64_t seed, double noise_scal
   if (!c->solved) return fail(c, "odef_sample: call odef_solve_* first");
   if (c->cfg.save_mode != ODEF_SAVE_EVERYSTEP) return fail(c, "odef_sample: needs ODEF_SAVE_EVERYSTEP (sampling not implemented for non-smoothed posteriors)");
   if (n_samples < 1 || n_samples > 65535) return fail(c, "odef_sample: n_samples must be in 1..65535");
-  if (c->team_path || c->D > 32) return fail(c, "odef_sample: built for state dimension <= 32 (got %d)", c->D);
+  if (!c->team_path && c->D > 32) return fail(c, "odef_sample: built for state dimension <= 32 and for the workgroup-per-trajectory path (got %d)", c->D);
   if (set_device(c)) return -1;
   c->n_samples = (long)n_samples;
   if (ensure(c, ODEF_F_SAMPLES, field_count(c, ODEF_F_SAMPLES, c->n_save) * sizeof(double))) return -1;
@@ -749,10 +749,12 @@ int odef_sample(odef_ctx* c, int64_t n_samples, uint64_t seed, double noise_scal
   S.noise_scale = noise_scale;
   S.samples = (double*)c->f[ODEF_F_SAMPLES].ptr;
   if (c->adaptive) HIPCHK(c, hipMemsetAsync(S.samples, 0, c->f[ODEF_F_SAMPLES].valid, c->stream));  // unused slots stay defined
+  if (c->team_path && ensure_ws(c, (size_t)dense_d28_grid(S.N * S.n_samples) * team_smooth_ws_doubles(c->d, c->q))) return -1;
   const long rows_tpb = c->jit ? 64 / c->jit->rows_team : 1;
   const int rc = c->jit ? (c->jit->posterior     ? jit_launch(c->jit->sample, (unsigned)((S.N + 63) / 64), (unsigned)S.n_samples, &S, c->stream)
                            : c->jit->sample_rows ? jit_launch(c->jit->sample_rows, (unsigned)((S.N * S.n_samples + rows_tpb - 1) / rows_tpb), 1, &S, c->stream)
                                                  : -3)
+                 : c->team_path ? launch_sample_d28(c->q, S, c->d_ws, c->stream)
                  : c->d == 2 ? launch_sample_d2(c->q, S, c->stream) : c->d == 3 ? launch_sample_d3(c->q, S, c->stream) : -3;
   if (rc) return fail(c, "odef_sample: no kernel for d %d order %d", c->d, c->q);
   HIPCHK(c, hipGetLastError());
@@ -786,10 +788,12 @@ int odef_dense_sample(odef_ctx* c, const double* tq, int64_t n_q, int64_t n_samp
   S.seed = (unsigned long long)seed;
   S.noise_scale = noise_scale;
   S.samples = (double*)c->f[ODEF_F_SAMPLES].ptr;
+  if (c->team_path && ensure_ws(c, (size_t)dense_d28_grid(S.N * S.n_samples) * team_smooth_ws_doubles(c->d, c->q))) return -1;
   const long rows_tpb = c->jit ? 64 / c->jit->rows_team : 1;
   const int rc = c->jit ? (c->jit->posterior     ? jit_launch(c->jit->sample, (unsigned)((S.N + 63) / 64), (unsigned)S.n_samples, &S, c->stream)
                            : c->jit->sample_rows ? jit_launch(c->jit->sample_rows, (unsigned)((S.N * S.n_samples + rows_tpb - 1) / rows_tpb), 1, &S, c->stream)
                                                  : -3)
+                 : c->team_path ? launch_sample_d28(c->q, S, c->d_ws, c->stream)
                  : c->d == 2 ? launch_sample_d2(c->q, S, c->stream) : c->d == 3 ? launch_sample_d3(c->q, S, c->stream) : -3;
   if (rc) return fail(c, "odef_dense_sample: no kernel for d %d order %d", c->d, c->q);
   HIPCHK(c, hipGetLastError());

@@ -20,6 +20,7 @@
 #include "sample_rows.h"
 #ifndef ODEF_HOST_EMUL
 #include "dense_mfma.h"
+#include "sample_mfma.h"
 #endif
 #include "launch.h"
 
@@ -343,7 +344,32 @@ __global__ __launch_bounds__(kTeamBig, 2) void dense_mfma_kernel(const DensePara
     __syncthreads();
   }
 }
+// Posterior sampling for the workgroup-per-trajectory path (sample_mfma.h): items = (trajectory, sample), same grid stride
+template <int d, int q>
+__global__ __launch_bounds__(kTeamBig, 2) void sample_mfma_kernel(const SampleParams P, double* ws) {
+  using W = MfmaSmoothWs<d, q + 1>;
+  __shared__ double lds[W::lds_size];
+  double* my = ws + (size_t)blockIdx.x * W::size;
+  for (size_t e = threadIdx.x; e < W::size; e += blockDim.x) my[e] = 0.0;  // padding and the zero "next" covariance (SG)
+  __syncthreads();
+  const long items = P.N * P.n_samples;
+  for (long it = (long)blockIdx.x; it < items; it += (long)gridDim.x) {
+    sample_mfma_item<d, q>(P, it % P.N, it / P.N, my, lds);
+    __syncthreads();
+  }
+}
 constexpr long kDenseMfmaMaxGrid = 1024;
+struct LaunchTeamSample {
+  const SampleParams& P;
+  double* ws;
+  hipStream_t s;
+  template <int d, int q>
+  void operator()() {
+    const long items = P.N * P.n_samples;
+    const unsigned grid = (unsigned)(items < kDenseMfmaMaxGrid ? items : kDenseMfmaMaxGrid);
+    hipLaunchKernelGGL((sample_mfma_kernel<d, q>), dim3(grid), dim3(kTeamBig), 0, s, P, ws);
+  }
+};
 struct LaunchTeamDense {
   const DenseParams& P;
   double* ws;

@@ -29,6 +29,10 @@ int launch_dense_d28(int q, const DenseParams& P, double* ws, hipStream_t s) {
   LaunchTeamDense f{P, ws, s};
   return dispatch_smooth_order<28>(q, f);
 }
+int launch_sample_d28(int q, const SampleParams& P, double* ws, hipStream_t s) {
+  LaunchTeamSample f{P, ws, s};
+  return dispatch_smooth_order<28>(q, f);
+}
 long dense_d28_grid(long items) { return items < kDenseMfmaMaxGrid ? items : kDenseMfmaMaxGrid; }
 size_t team_filter_ws_doubles(int d, int q) {
   if (d != 28) return 0;

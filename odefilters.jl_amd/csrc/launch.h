@@ -30,6 +30,7 @@ int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStrea
 int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s);
 int launch_dense_d28(int q, const DenseParams& P, double* ws, hipStream_t s);  // ws: dense_d28_grid(N n_q) x team_smooth_ws_doubles
 long dense_d28_grid(long items);
+int launch_sample_d28(int q, const SampleParams& P, double* ws, hipStream_t s);  // ws: dense_d28_grid(N n_samples) x team_smooth_ws_doubles
 size_t team_filter_ws_doubles(int d, int q);
 size_t team_smooth_ws_doubles(int d, int q);
 }  // namespace odef

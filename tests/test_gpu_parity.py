@@ -659,6 +659,37 @@ def test_posterior_sampling_row_teams(pkg, q):
     assert ds.shape == (N, len(tq), D, 4) and np.isfinite(ds).all()
 
 
+@pytest.mark.parametrize("q", [2, 5])
+def test_posterior_sampling_pleiades(pkg, q):
+    """sample_states on the workgroup-per-trajectory path (state dimension 84 / 168, csrc/sample_mfma.h): at order 2 value by value
+    against the oracle with the same noise stream and square root; at both orders the zero-noise chain of conditional means is
+    the smoothed mean, draws are finite and reproducible, and the dense-grid mode runs."""
+    vf = orc.vector_field("pleiades")
+    D = 28 * (q + 1)
+    N, ns_, dt, n, seed = 2, 8, 2.0**-10, 3, 777
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("pleiades", vf.u0, (0.0, ns_ * dt), ()), perturb_scale=1e-3, n_perturbed=14)
+    sol = pkg.solve(ens, pkg.EK1(order=q), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
+    st = sol.sample_states(n, seed)
+    cap = st.shape[1]
+    assert st.shape == (N, cap, D, n) and np.isfinite(st).all()
+    z = sol.sample_states(1, seed, noise_scale=0.0)[..., 0]
+    np.testing.assert_allclose(z[:, 1:, :28], sol.x_smooth_mean()[:, 1:, :28], rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(sol.sample_states(n, seed), st)
+    assert not np.array_equal(sol.sample_states(n, seed + 1), st)
+    if q == 2:
+        u0s = orc.ensemble_u0(vf.u0, N, 1e-3, n_perturbed=14)
+        consts = orc.make_consts(28, q)
+        for i in (0, 1):
+            ref = orc.solve(vf, orc.EK1(order=q), u0=u0s[i], tspan=(0.0, ns_ * dt), dt=dt)
+            want = orc.sample_states(ref, consts, n, sqrt="cholesky", normal=lambda j, slot, k: orc.sample_normal(seed, i, j, slot, k, n, cap, D))
+            scale = np.abs(want).max(axis=(0, 2))[None, :, None]
+            err = (np.abs(st[i, :len(ref.t)] - want) / scale).max(axis=(0, 2))
+            assert err[:28].max() < 1e-7 and err.max() < 1e-2, err
+    tq = np.linspace(0.0, ns_ * dt, 7)
+    ds, _ = sol.dense_sample_states(2, seed, times=tq)
+    assert ds.shape == (N, len(tq), D, 2) and np.isfinite(ds).all()
+
+
 @pytest.mark.parametrize("adaptive", [False, True])
 def test_dense_posterior_sampling(pkg, adaptive):
     """dense_sample / dense_sample_states (src/solution_sampling.jl:63-75) against the oracle with the same noise stream
