@@ -324,5 +324,132 @@ __device__ inline void wg_solve_upper(const double* __restrict__ Um, const doubl
   }
 }
 
+// ---- register-resident variants (round 2, second half): the right-hand sides / the B operand stay in the accumulator
+// registers of the wavefront that owns their tile COLUMN, for the whole sweep / product.  Columns are independent in
+// both, so there is no barrier inside; the shared operand (U, L, M, Z) streams from L2 as k-major fragments.  With four
+// wavefronts and 256 registers a wavefront can hold two tile columns (2 x DPB tiles): DPB = 11 columns go in two passes
+// (columns 0..7 two per wavefront, then 8..10 one per wavefront).
+// MEASURED (tools/mfma_dense_test.hip and the D = 168 smoother, -DODEF_SMOOTH_RR): correct to 2e-15 and SLOWER than the
+// left-looking forms above -- 509 against 410 us for one workgroup, 529 against 352 ms for 2 048 trajectories x 64 steps.
+// The barriers it removes were not the cost: with two columns resident a wavefront has 22 dependent accumulator chains
+// but no registers left to keep the next k-major fragments in flight, so every 4-load group is waited for (L2 latency per
+// block pair), and the operand traffic is the same (every wavefront streams all of U / L / M per pass).  Kept for the
+// record and for a layout with fewer, wider wavefronts; not used by default.
+template <int DPB>
+struct ColPass {
+  static constexpr int kPasses = (DPB + 7) / 8;
+  // columns of (wave, pass): c0 always valid if n >= 1
+  __device__ static inline int ncols(int wave, int pass) {
+    const int first = 8 * pass, rest = DPB - first;
+    if (rest >= 8) return 2;
+    // the last pass: `rest` (< 8) columns, one per wavefront first, then a second one
+    return (wave < rest ? 1 : 0) + (wave + 4 < rest ? 1 : 0);
+  }
+  __device__ static inline int col(int wave, int pass, int t) {
+    const int first = 8 * pass, rest = DPB - first;
+    if (rest >= 8) return first + 2 * wave + t;
+    return first + wave + 4 * t;
+  }
+};
+
+// Gt <- (U'U)^-1 Yt in place, as wg_solve_upper, but RIGHT-looking with the right-hand sides resident: per pass a
+// wavefront loads its <= 2 tile columns of Yt (2 x DPB tiles), runs the forward sweep (Z_j = W_j acc_j, then
+// acc_j' -= U[j, j']' Z_j for j' > j), the backward sweep (Gt_j = W_j' acc_j, then acc_j' -= U[j', j] Gt_j for j' < j,
+// read k-major from L = U'), and stores them.  No barrier: 22 block steps of the left-looking form each ended in one.
+template <int DPB>
+__device__ inline void wg_solve_upper_rr(const double* __restrict__ Um, const double* __restrict__ Lm, double* __restrict__ Yt, int ld,
+                                         const double* __restrict__ lds) {
+  using LL = CholLds<DPB>;
+  const int wave = (int)(threadIdx.x >> 6);
+  for (int pass = 0; pass < ColPass<DPB>::kPasses; ++pass) {
+    const int nc = ColPass<DPB>::ncols(wave, pass);
+    if (nc == 0) continue;
+    const int c0 = ColPass<DPB>::col(wave, pass, 0) * kB, c1 = (nc > 1 ? ColPass<DPB>::col(wave, pass, 1) : ColPass<DPB>::col(wave, pass, 0)) * kB;
+    d4 acc[DPB][2];
+#pragma unroll
+    for (int j = 0; j < DPB; ++j) {
+      acc[j][0] = load_tile(Yt, ld, j * kB, c0);
+      acc[j][1] = load_tile(Yt, ld, j * kB, c1);  // (a lone column is carried twice: same code, no branches in the sweeps)
+    }
+    static_for<0, DPB>([&](auto jc) {  // forward
+      constexpr int j = decltype(jc)::value;
+      const double* wj = lds + LL::w + j * kB * kB;
+      const d4 z0 = apply_w<false>(wj, acc[j][0]), z1 = apply_w<false>(wj, acc[j][1]);
+      acc[j][0] = z0;
+      acc[j][1] = z1;
+      static_for<j + 1, DPB>([&](auto jpc) {
+        constexpr int jp = decltype(jpc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const double a = -frag(Um, ld, j * kB + 4 * ks, jp * kB);
+          acc[jp][0] = mfma(a, z0[ks], acc[jp][0]);
+          acc[jp][1] = mfma(a, z1[ks], acc[jp][1]);
+        }
+      });
+    });
+    static_for<0, DPB>([&](auto jc) {  // backward
+      constexpr int j = DPB - 1 - decltype(jc)::value;
+      const double* wj = lds + LL::w + j * kB * kB;
+      const d4 g0 = apply_w<true>(wj, acc[j][0]), g1 = apply_w<true>(wj, acc[j][1]);
+      acc[j][0] = g0;
+      acc[j][1] = g1;
+      static_for<0, j>([&](auto jpc) {
+        constexpr int jp = decltype(jpc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const double a = -frag(Lm, ld, j * kB + 4 * ks, jp * kB);
+          acc[jp][0] = mfma(a, g0[ks], acc[jp][0]);
+          acc[jp][1] = mfma(a, g1[ks], acc[jp][1]);
+        }
+      });
+    });
+#pragma unroll
+    for (int j = 0; j < DPB; ++j) {
+      store_tile(Yt, ld, j * kB, c0, acc[j][0]);
+      if (nc > 1) store_tile(Yt, ld, j * kB, c1, acc[j][1]);
+    }
+  }
+}
+
+// C = A'B (DPB x DPB tiles, all row-major with the same leading dimension) with the tile columns of B resident in the
+// registers of their wavefront: per pass a wavefront loads its <= 2 tile columns of B once and produces the same columns
+// of C, two tile rows at a time, from k-major fragments of A.
+template <int DPB>
+__device__ inline void wg_atb_rescols(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int ld) {
+  const int wave = (int)(threadIdx.x >> 6);
+  for (int pass = 0; pass < ColPass<DPB>::kPasses; ++pass) {
+    const int nc = ColPass<DPB>::ncols(wave, pass);
+    if (nc == 0) continue;
+    const int c0 = ColPass<DPB>::col(wave, pass, 0) * kB, c1 = (nc > 1 ? ColPass<DPB>::col(wave, pass, 1) : ColPass<DPB>::col(wave, pass, 0)) * kB;
+    d4 b[DPB][2];
+#pragma unroll
+    for (int k = 0; k < DPB; ++k) {
+      b[k][0] = load_tile(B, ld, k * kB, c0);
+      b[k][1] = load_tile(B, ld, k * kB, c1);
+    }
+    for (int r = 0; r < DPB; r += 2) {
+      const int r1 = r + 1 < DPB ? r + 1 : r;
+      d4 o00 = zero4(), o01 = zero4(), o10 = zero4(), o11 = zero4();
+      static_for<0, DPB>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const double a0 = frag(A, ld, k * kB + 4 * ks, r * kB), a1 = frag(A, ld, k * kB + 4 * ks, r1 * kB);
+          o00 = mfma(a0, b[k][0][ks], o00);
+          o01 = mfma(a0, b[k][1][ks], o01);
+          o10 = mfma(a1, b[k][0][ks], o10);
+          o11 = mfma(a1, b[k][1][ks], o11);
+        }
+      });
+      store_tile(C, ld, r * kB, c0, o00);
+      if (nc > 1) store_tile(C, ld, r * kB, c1, o01);
+      if (r1 != r) {
+        store_tile(C, ld, r1 * kB, c0, o10);
+        if (nc > 1) store_tile(C, ld, r1 * kB, c1, o11);
+      }
+    }
+  }
+}
+
 }  // namespace mf
 }  // namespace odef

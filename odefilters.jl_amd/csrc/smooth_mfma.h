@@ -176,7 +176,12 @@ __device__ inline bool mfma_gain_phase(double* __restrict__ ws, double* __restri
   // B = U'U, Gt = B^-1 Yt (the gain G = X A' (Sigma^-)^-1, src/smoothing.jl:42-43, transposed)
   mf::wg_cholesky_upper<DPB>(BM, LM, DP, lds);
   ODEF_STAMP(3);  // Cholesky
-  mf::wg_solve_upper<DPB>(BM, LM, YT, DP, lds);
+#ifndef ODEF_SMOOTH_RR
+  mf::wg_solve_upper<DPB>(BM, LM, YT, DP, lds);  // left-looking: 22 block steps, a barrier after each
+#else  // A/B build: right-hand sides resident in the accumulators, no barrier inside -- measured 1.5x SLOWER (see mfma_dense.h)
+  mf::wg_solve_upper_rr<DPB>(BM, LM, YT, DP, lds);
+  __syncthreads();
+#endif
   ODEF_STAMP(4);  // sweeps
   // m^s = m + G delta (src/smoothing.jl:44), un-preconditioned (:26)
   for (int k = tid; k < D; k += nth) {
@@ -189,10 +194,18 @@ __device__ inline bool mfma_gain_phase(double* __restrict__ ws, double* __restri
   }
   // Z = M Gt, R = Z' Gt = G M G'
   ODEF_STAMP(5);  // mean
+#ifndef ODEF_SMOOTH_RR
   mf::wg_atb<false>(MM, DP, YT, DP, DP, nullptr, Z2, DP, 0, DPB, 0, DPB);
+#else
+  mf::wg_atb_rescols<DPB>(MM, YT, Z2, DP);
+#endif
   __syncthreads();
   ODEF_STAMP(6);  // Z = M Gt
+#ifndef ODEF_SMOOTH_RR
   mf::wg_atb<false>(Z2, DP, YT, DP, DP, nullptr, BM, DP, 0, DPB, 0, DPB);
+#else
+  mf::wg_atb_rescols<DPB>(Z2, YT, BM, DP);
+#endif
   __syncthreads();
   ODEF_STAMP(7);  // R = Z' Gt
   return nan_seen;

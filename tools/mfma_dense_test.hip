@@ -12,11 +12,19 @@ constexpr int D = 168, DPB = 11, DP = DPB * 16;
 __global__ __launch_bounds__(256) void k_test(double* Bm, double* Lm, double* Yt, const double* M, double* Z2, double* R) {
   __shared__ double lds[mf::CholLds<DPB>::size];
   mf::wg_cholesky_upper<DPB>(Bm, Lm, DP, lds);
+#ifndef TEST_RR  // the forms the smoother uses (block rows, a barrier after each; 3 x 2 tile strips)
   mf::wg_solve_upper<DPB>(Bm, Lm, Yt, DP, lds);
   __syncthreads();
   mf::wg_atb<false>(M, DP, Yt, DP, DP, nullptr, Z2, DP, 0, DPB, 0, DPB);   // Z2 = M' Gt
   __syncthreads();
   mf::wg_atb<false>(Z2, DP, Yt, DP, DP, nullptr, R, DP, 0, DPB, 0, DPB);   // R = Z2' Gt
+#else            // the register-resident variants (build with -DTEST_RR): same results, slower
+  mf::wg_solve_upper_rr<DPB>(Bm, Lm, Yt, DP, lds);
+  __syncthreads();
+  mf::wg_atb_rescols<DPB>(M, Yt, Z2, DP);   // Z2 = M' Gt
+  __syncthreads();
+  mf::wg_atb_rescols<DPB>(Z2, Yt, R, DP);   // R = Z2' Gt
+#endif
 }
 
 int main() {
