@@ -13,7 +13,7 @@ for k in 1 2 3; do python3 bench.py > $OUT/bench_$k.json 2>$OUT/bench_$k.err; cu
 python3 tools/bench_modes.py --traj 2048 --nsteps 64 --modes pleiades_smooth > $OUT/pleiades_smooth.json 2>>$OUT/configs.err
 ODEF_PLEIADES_SMOOTH=team python3 tools/bench_modes.py --traj 2048 --nsteps 64 --modes pleiades_smooth >> $OUT/pleiades_smooth.json 2>>$OUT/configs.err
 cat $OUT/pleiades_smooth.json | cut -c1-300
-timeout -k 5 100 tools/mfma_filter_stamps > $OUT/mfma_filter_stamps.txt 2>&1; timeout -k 5 100 tools/mfma_smooth_stamps 2048 > $OUT/mfma_smooth_stamps.txt 2>&1
+timeout -k 5 100 tools/mfma_filter_stamps > $OUT/mfma_filter_stamps.txt 2>&1
 timeout -k 5 60 tools/mfma_dense_test > $OUT/mfma_dense_test.txt 2>&1; timeout -k 5 60 tools/mfma_layout_test > $OUT/mfma_layout_test.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_prof_line.json 2>$OUT/bench_prof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg4 -- python3 tools/configs_r02.py --only 4 --reps 4 > /dev/null 2>$OUT/cfg4.err
