@@ -261,7 +261,9 @@ __global__ __launch_bounds__(kTeamBig) void ek_filter_team_kernel(const TeamFilt
 }
 template <int d, int q>
 __global__ __launch_bounds__(kTeamBig) void rts_smooth_team_kernel(const SmoothParams P, double* ws) {
-  smooth_team_lane<d, q, kTeamBig>(P, (long)blockIdx.x, (int)threadIdx.x, ws + (size_t)blockIdx.x * SmoothWs<d, q + 1>::size);
+  const long i = team_traj(P.N);
+  if (i < 0) return;
+  smooth_team_lane<d, q, kTeamBig>(P, i, (int)threadIdx.x, ws + (size_t)i * SmoothWs<d, q + 1>::size);
 }
 
 // Register-tiled workgroup-per-trajectory filter (filter_tiles.h): 320 threads with one 7 x 7 covariance tile each
@@ -271,20 +273,24 @@ __global__ __launch_bounds__(kTilesBlock) void ek_filter_tiles_kernel(const Filt
   using TF = TilesFilter<RHS, q, EK1>;
   __shared__ double sm[TF::W::size];
   TileState st;
+  const long i = team_traj(P.N);
+  if (i < 0) return;
   if (threadIdx.x >= kTilesThreads)  // the helper wavefront: same barriers, its own code path
-    TF::template run<true>(P, (long)blockIdx.x, (int)threadIdx.x, sm, &st);
+    TF::template run<true>(P, i, (int)threadIdx.x, sm, &st);
   else
-    TF::template run<false>(P, (long)blockIdx.x, (int)threadIdx.x, sm, &st);
+    TF::template run<false>(P, i, (int)threadIdx.x, sm, &st);
 }
 template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kTilesBlock) void ek_filter_tiles_adaptive_kernel(const FilterParams P) {
   using TF = TilesFilter<RHS, q, EK1>;
   __shared__ double sm[TF::W::size];
   TileState st;
+  const long i = team_traj(P.N);
+  if (i < 0) return;
   if (threadIdx.x >= kTilesThreads)
-    TF::template run_adaptive<true>(P, (long)blockIdx.x, (int)threadIdx.x, sm, &st);
+    TF::template run_adaptive<true>(P, i, (int)threadIdx.x, sm, &st);
   else
-    TF::template run_adaptive<false>(P, (long)blockIdx.x, (int)threadIdx.x, sm, &st);
+    TF::template run_adaptive<false>(P, i, (int)threadIdx.x, sm, &st);
 }
 // ODEF_PLEIADES_FILTER=tiles selects the register-tiled VALU kernel for fixed-step solves too (default: the MFMA
 // kernel of filter_mfma.h; adaptive solves always run on the tiled kernel)
@@ -299,13 +305,13 @@ struct LaunchTilesFilter {
   template <class RHS, int q, bool EK1>
   void operator()() {
     if (!adaptive && !pleiades_filter_tiles()) {
-      hipLaunchKernelGGL((ek_filter_mfma_kernel<RHS, q, EK1>), dim3((unsigned)P.N), dim3(kMfBlock), 0, s, P);
+      hipLaunchKernelGGL((ek_filter_mfma_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kMfBlock), 0, s, P);
       return;
     }
     if (adaptive)
-      hipLaunchKernelGGL((ek_filter_tiles_adaptive_kernel<RHS, q, EK1>), dim3((unsigned)P.N), dim3(kTilesBlock), 0, s, P);
+      hipLaunchKernelGGL((ek_filter_tiles_adaptive_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kTilesBlock), 0, s, P);
     else
-      hipLaunchKernelGGL((ek_filter_tiles_kernel<RHS, q, EK1>), dim3((unsigned)P.N), dim3(kTilesBlock), 0, s, P);
+      hipLaunchKernelGGL((ek_filter_tiles_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kTilesBlock), 0, s, P);
   }
 };
 
@@ -322,7 +328,9 @@ template <int d, int q>
 __global__ __launch_bounds__(kTeamBig, 2) void rts_smooth_mfma_kernel(const SmoothParams P, double* ws) {  // two workgroups per CU: the phases are latency-bound
   using W = MfmaSmoothWs<d, q + 1>;
   __shared__ double lds[W::lds_size];
-  smooth_mfma_traj<d, q>(P, (long)blockIdx.x, ws + (size_t)blockIdx.x * W::size, lds);
+  const long i = team_traj(P.N);
+  if (i < 0) return;
+  smooth_mfma_traj<d, q>(P, i, ws + (size_t)i * W::size, lds);
 }
 inline bool pleiades_smooth_team() {  // ODEF_PLEIADES_SMOOTH=team: the first (vector-FMA) D = 168 smoother, for A/B comparison
   const char* e = getenv("ODEF_PLEIADES_SMOOTH");
@@ -390,9 +398,9 @@ struct LaunchTeamSmooth {
   template <int d, int q>
   void operator()() {
     if (pleiades_smooth_team())
-      hipLaunchKernelGGL((rts_smooth_team_kernel<d, q>), dim3((unsigned)P.N), dim3(kTeamBig), 0, s, P, ws);
+      hipLaunchKernelGGL((rts_smooth_team_kernel<d, q>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
     else
-      hipLaunchKernelGGL((rts_smooth_mfma_kernel<d, q>), dim3((unsigned)P.N), dim3(kTeamBig), 0, s, P, ws);
+      hipLaunchKernelGGL((rts_smooth_mfma_kernel<d, q>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
   }
 };
 

@@ -41,6 +41,19 @@
 
 namespace odef {
 
+// The same map for the workgroup-per-trajectory kernels (D = 168): consecutive trajectories sit next to each other in every
+// record row ([field][N] layout: 8 bytes apart), so the 8-byte pieces a workgroup stores or loads share their 64-byte sector with
+// the 7 neighbouring trajectories.  With the plain map those neighbours run on 8 different XCDs -- 8 L2s each holding one piece
+// of the sector, every piece a partial write / a whole sector fetched for 8 bytes.  Giving each XCD a contiguous range of
+// trajectories puts the neighbours into ONE L2 at about the same time, where the pieces merge.  Grid: team_grid(N) workgroups;
+// returns -1 for the padding workgroups.
+inline unsigned team_grid(long N) { return (unsigned)((N + 7) / 8 * 8); }
+__device__ inline long team_traj(long N) {
+  const long per = (long)(gridDim.x / 8u);
+  const long i = (long)(blockIdx.x % 8u) * per + (long)(blockIdx.x / 8u);
+  return i < N ? i : -1;
+}
+
 constexpr int kMfWaves = 9;       // wavefronts of the workgroup
 constexpr int kMfTileWaves = 8;   // ... that own tiles; the last one is the helper
 constexpr int kMfHelper = 8;
@@ -1007,10 +1020,12 @@ template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kMfBlock) void ek_filter_mfma_kernel(const FilterParams P) {
   using MF = MfmaFilter<RHS, q, EK1>;
   __shared__ double sm[MF::W::size];
+  const long i = team_traj(P.N);  // XCD-aware: neighbouring trajectories share an L2
+  if (i < 0) return;
   if (threadIdx.x >= 64 * kMfHelper)  // the helper wavefront: same barriers, its own code path and register allocation
-    MF::template run<true>(P, (long)blockIdx.x, (int)threadIdx.x, sm);
+    MF::template run<true>(P, i, (int)threadIdx.x, sm);
   else
-    MF::template run<false>(P, (long)blockIdx.x, (int)threadIdx.x, sm);
+    MF::template run<false>(P, i, (int)threadIdx.x, sm);
 }
 
 }  // namespace odef
