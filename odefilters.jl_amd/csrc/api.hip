@@ -67,6 +67,8 @@ struct odef_ctx {
   bool team_path = false;   // workgroup-per-trajectory kernels (large state dimension)
   JitModule* jit = nullptr; // run-time compiled vector field (rhs_id >= 100); owned by the registry in jit.hip
   double* d_ws = nullptr;   // per-trajectory workspace of the team kernels
+  double* d_stage = nullptr;  // trajectory-major stage of the covariance records (D = 168 smoother, record_stage.h)
+  size_t stage_cap = 0;     // doubles
   size_t ws_cap = 0;
   Buf f[ODEF_F_COUNT_];
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -184,6 +186,35 @@ int ensure_ws(odef_ctx* c, size_t doubles) {
   HIPCHK(c, hipMalloc((void**)&c->d_ws, doubles * sizeof(double)));
   c->ws_cap = doubles;
   return 0;
+}
+
+// Stage for the workgroup-per-trajectory smoother: as many records as fit in `ODEF_SMOOTH_STAGE_MB` (default: a third of
+// the free device memory), at most the n_save - 1 the pass touches.  Returns the capacity in doubles (0: run in place).
+size_t ensure_stage(odef_ctx* c, long n_save, size_t per_rec_doubles) {
+  if (n_save < 3) return 0;
+  size_t budget;
+  if (const char* e = getenv("ODEF_SMOOTH_STAGE_MB")) {
+    budget = (size_t)atol(e) << 20;
+  } else {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    budget = (free_b + c->stage_cap * sizeof(double)) / 3;
+  }
+  size_t recs = budget / (per_rec_doubles * sizeof(double));
+  if (recs > (size_t)(n_save - 1)) recs = (size_t)(n_save - 1);
+  if (recs < 2) return 0;
+  const size_t doubles = recs * per_rec_doubles;
+  if (c->stage_cap < doubles) {
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    c->d_stage = nullptr;
+    c->stage_cap = 0;
+    if (hipMalloc((void**)&c->d_stage, doubles * sizeof(double)) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    c->stage_cap = doubles;
+  }
+  return doubles;
 }
 
 int set_device(odef_ctx* c) {
@@ -340,6 +371,7 @@ void odef_destroy(odef_ctx* c) {
   if (c->d_u0) (void)hipFree(c->d_u0);
   if (c->d_p) (void)hipFree(c->d_p);
   if (c->d_ws) (void)hipFree(c->d_ws);
+  if (c->d_stage) (void)hipFree(c->d_stage);
   if (c->d_hs) (void)hipFree(c->d_hs);
   if (c->d_ptab) (void)hipFree(c->d_ptab);
   if (c->d_tgrid) (void)hipFree(c->d_tgrid);
@@ -658,8 +690,16 @@ int odef_smooth(odef_ctx* c) {
       rc = jit_launch(c->jit->smooth_rows, (unsigned)((S.N + tpb - 1) / tpb), 1, &S, c->stream);
     } else
       rc = -3;
-  else
-    rc = c->team_path ? launch_smooth_d28(c->q, S, c->d_ws, c->stream) : launch_smooth(c->d, c->q, S, c->stream);
+  else if (c->team_path) {
+    rc = -4;
+    if (!S.adaptive) {  // fixed grid: records through the trajectory-major stage, in chunks (record_stage.h)
+      const size_t tri = (size_t)c->D * (c->D + 1) / 2;
+      const size_t have = ensure_stage(c, S.n_save, (size_t)S.N * ((tri + 15) / 16 * 16));
+      if (have) rc = launch_smooth_d28_staged(c->q, S, c->d_ws, c->d_stage, have, c->stream);
+    }
+    if (rc == -4) rc = launch_smooth_d28(c->q, S, c->d_ws, c->stream);
+  } else
+    rc = launch_smooth(c->d, c->q, S, c->stream);
   if (rc) return fail(c, "odef_smooth: no kernel for d %d order %d", c->d, c->q);
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   HIPCHK(c, hipGetLastError());

@@ -12,6 +12,7 @@
 #include "sample_lane.h"
 #include "filter_team.h"
 #include "filter_tiles.h"
+#include "record_stage.h"
 #include "filter_mfma.h"
 #include "rows_filter.h"
 #include "rows_smooth.h"

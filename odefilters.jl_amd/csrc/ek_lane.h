@@ -388,6 +388,13 @@ struct SmoothParams {
   double* smean;        // outputs, same layout
   double* scov;
   int* retcode;
+  // workgroup-per-trajectory matrix-core smoother only (smooth_mfma.h): covariance records staged trajectory-major, so
+  // that a workgroup reads and writes its records as contiguous lines (null: the records are used where they lie)
+  double* stage;   // [records stage_s0 ..][N][stage_ld]: filter covariances in, smoothed covariances out (in place)
+  long stage_s0;   // save index of the first staged record
+  long stage_ld;   // doubles per staged record (the packed triangle rounded up to whole 128-byte lines)
+  long s_lo, s_hi; // this launch smooths records s_hi, s_hi - 1, .., s_lo
+  int resume;      // 0: first launch of the pass (the carried state starts from the last record); 1: continue
 };
 
 }  // namespace odef

@@ -411,6 +411,44 @@ __device__ inline void wg_solve_upper_rr(const double* __restrict__ Um, const do
   }
 }
 
+// The same with ONE tile column per wavefront and pass (DPB tiles = 8 DPB registers): small enough for four workgroups
+// per CU (128 registers), so the dependent chain of a column -- apply W_j, update the DPB - 1 - j tiles below -- is hidden
+// by the other wavefronts of the SIMD instead of by loads in flight.  Columns go round-robin over the wavefronts.
+template <int DPB>
+__device__ inline void wg_solve_upper_col(const double* __restrict__ Um, const double* __restrict__ Lm, double* __restrict__ Yt, int ld,
+                                          const double* __restrict__ lds) {
+  using LL = CholLds<DPB>;
+  const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6);
+  for (int cb = wave; cb < DPB; cb += nwaves) {
+    const int c0 = cb * kB;
+    d4 acc[DPB];
+#pragma unroll
+    for (int j = 0; j < DPB; ++j) acc[j] = load_tile(Yt, ld, j * kB, c0);
+    static_for<0, DPB>([&](auto jc) {  // forward: Z_j = W_j acc_j, acc_j' -= U[j, j']' Z_j for j' > j
+      constexpr int j = decltype(jc)::value;
+      const d4 z = apply_w<false>(lds + LL::w + j * kB * kB, acc[j]);
+      acc[j] = z;
+      static_for<j + 1, DPB>([&](auto jpc) {
+        constexpr int jp = decltype(jpc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc[jp] = mfma(-frag(Um, ld, j * kB + 4 * ks, jp * kB), z[ks], acc[jp]);
+      });
+    });
+    static_for<0, DPB>([&](auto jc) {  // backward: Gt_j = W_j' acc_j, acc_j' -= U[j', j] Gt_j for j' < j (k-major in L = U')
+      constexpr int j = DPB - 1 - decltype(jc)::value;
+      const d4 g = apply_w<true>(lds + LL::w + j * kB * kB, acc[j]);
+      acc[j] = g;
+      static_for<0, j>([&](auto jpc) {
+        constexpr int jp = decltype(jpc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc[jp] = mfma(-frag(Lm, ld, j * kB + 4 * ks, jp * kB), g[ks], acc[jp]);
+      });
+    });
+#pragma unroll
+    for (int j = 0; j < DPB; ++j) store_tile(Yt, ld, j * kB, c0, acc[j]);
+  }
+}
+
 // C = A'B (DPB x DPB tiles, all row-major with the same leading dimension) with the tile columns of B resident in the
 // registers of their wavefront: per pass a wavefront loads its <= 2 tile columns of B once and produces the same columns
 // of C, two tile rows at a time, from k-major fragments of A.

@@ -44,7 +44,8 @@ template <int d, int NB>
 struct MfmaSmoothWs {
   static constexpr int D = d * NB, DPB = (D + 15) / 16, DP = DPB * 16, MAT = DP * DP;
   static constexpr int X = 0, YT = MAT, BM = 2 * MAT, LM = 3 * MAT, MM = 4 * MAT, Z2 = 5 * MAT, SG = 6 * MAT;
-  static constexpr size_t size = 7 * (size_t)MAT;
+  static constexpr int MSV = 7 * MAT;  // the carried smoothed mean between the launches of a staged pass
+  static constexpr size_t size = 7 * (size_t)MAT + DP;
   // LDS (doubles): factorisation scratch, then the vectors
   static constexpr int kChol = mf::CholLds<DPB>::size;
   static constexpr int MF = kChol, MS = MF + DP, MP = MS + DP, DL = MP + DP, PJ = DL + DP, PIJ = PJ + DP;
@@ -176,7 +177,10 @@ __device__ inline bool mfma_gain_phase(double* __restrict__ ws, double* __restri
   // B = U'U, Gt = B^-1 Yt (the gain G = X A' (Sigma^-)^-1, src/smoothing.jl:42-43, transposed)
   mf::wg_cholesky_upper<DPB>(BM, LM, DP, lds);
   ODEF_STAMP(3);  // Cholesky
-#ifndef ODEF_SMOOTH_RR
+#if defined(ODEF_SMOOTH_COL)
+  mf::wg_solve_upper_col<DPB>(BM, LM, YT, DP, lds);
+  __syncthreads();
+#elif !defined(ODEF_SMOOTH_RR)
   mf::wg_solve_upper<DPB>(BM, LM, YT, DP, lds);  // left-looking: 22 block steps, a barrier after each
 #else  // A/B build: right-hand sides resident in the accumulators, no barrier inside -- measured 1.5x SLOWER (see mfma_dense.h)
   mf::wg_solve_upper_rr<DPB>(BM, LM, YT, DP, lds);
@@ -234,35 +238,61 @@ __device__ inline void smooth_mfma_traj(const SmoothParams& P, long i, double* _
   double* pj_ = lds + W::PJ;
   double* pij_ = lds + W::PIJ;
 
-  // zero the workspace once (padding rows / columns stay zero from here on); L = U' must be zero above the diagonal
-  for (size_t e = tid; e < W::size; e += nth) ws[e] = 0.0;
-  __syncthreads();
-  // first and last record are copied (index 1 in Julia is never smoothed, src/smoothing.jl:11); the last one is the
-  // carried smoothed state Sigma^s (SG, full symmetric, un-preconditioned)
-  for (int w = 0; w < 2; ++w) {
-    const long s = w == 0 ? 0 : n - 1;
-    for (int k = tid; k < D; k += nth) {
-      const double v = P.mean[((size_t)s * D + k) * N + i];
-      P.smean[((size_t)s * D + k) * N + i] = v;
-      ms_[k] = v;
+  // Staged pass (fixed grids, api.hip): the covariance records of this launch lie trajectory-major in P.stage -- one record is
+  // stage_ld contiguous doubles, read and written as whole lines -- instead of as 8-byte pieces N doubles apart.
+  const bool staged = P.stage != nullptr;
+  const long s_hi = staged ? P.s_hi : n - 2, s_lo = staged ? P.s_lo : 1;
+  auto rec = [&](long s) -> double* { return P.stage + ((size_t)(s - P.stage_s0) * N + (size_t)i) * (size_t)P.stage_ld; };
+  if (!staged || !P.resume) {
+    // zero the workspace once (padding rows / columns stay zero from here on); L = U' must be zero above the diagonal
+    for (size_t e = tid; e < W::size; e += nth) ws[e] = 0.0;
+    __syncthreads();
+    // first and last record are copied (index 1 in Julia is never smoothed, src/smoothing.jl:11); the last one is the
+    // carried smoothed state Sigma^s (SG, full symmetric, un-preconditioned)
+    for (int w = 0; w < 2; ++w) {
+      const long s = w == 0 ? 0 : n - 1;
+      for (int k = tid; k < D; k += nth) {
+        const double v = P.mean[((size_t)s * D + k) * N + i];
+        P.smean[((size_t)s * D + k) * N + i] = v;
+        ms_[k] = v;
+      }
+      if (staged) {  // the two covariance records are copied by the host; the last one is staged for this read
+        if (w == 0) continue;
+        const double* src = rec(s);
+        TriWalk tw(tid);
+        for (int e = tid; e < TRI; e += nth, tw.advance(nth)) {
+          const double v = src[e];
+          SG[tw.a * DP + tw.b] = v;
+          SG[tw.b * DP + tw.a] = v;
+        }
+        continue;
+      }
+      TriWalk tw(tid);
+      for (int e = tid; e < TRI; e += nth, tw.advance(nth)) {
+        const double v = P.cov[((size_t)s * TRI + e) * N + i];
+        P.scov[((size_t)s * TRI + e) * N + i] = v;
+        SG[tw.a * DP + tw.b] = v;
+        SG[tw.b * DP + tw.a] = v;
+      }
     }
-    TriWalk tw(tid);
-    for (int e = tid; e < TRI; e += nth, tw.advance(nth)) {
-      const double v = P.cov[((size_t)s * TRI + e) * N + i];
-      P.scov[((size_t)s * TRI + e) * N + i] = v;
-      SG[tw.a * DP + tw.b] = v;
-      SG[tw.b * DP + tw.a] = v;
-    }
+  } else {
+    for (int k = tid; k < D; k += nth) ms_[k] = ws[W::MSV + k];
   }
   __syncthreads();
   bool nan_seen = false;
-  for (long s = n - 2; s >= 1; --s) {
+  for (long s = s_hi; s >= s_lo; --s) {
     double h;
     if (P.adaptive) h = P.tsave[(size_t)(s + 1) * N + i] - P.tsave[(size_t)s * N + i];
     else h = uniform_load(P.hs + s);
     if (h == 0.0) {  // src/smoothing.jl:13-16: a repeated save time, the smoothed state carries over
       for (int k = tid; k < D; k += nth) P.smean[((size_t)s * D + k) * N + i] = ms_[k];
-      for (int e = tid; e < TRI; e += nth) P.scov[((size_t)s * TRI + e) * N + i] = P.scov[((size_t)(s + 1) * TRI + e) * N + i];
+      if (staged) {
+        double* dst = rec(s);
+        TriWalk tw(tid);
+        for (int e = tid; e < TRI; e += nth, tw.advance(nth)) dst[e] = SG[tw.a * DP + tw.b];
+      } else {
+        for (int e = tid; e < TRI; e += nth) P.scov[((size_t)s * TRI + e) * N + i] = P.scov[((size_t)(s + 1) * TRI + e) * N + i];
+      }
       __syncthreads();
       continue;
     }
@@ -289,10 +319,11 @@ __device__ inline void smooth_mfma_traj(const SmoothParams& P, long i, double* _
     // X = P Sigma_i P (src/smoothing.jl:23), m~ = P m_i
     {
       TriWalk tw(tid);
-      const double* src = P.cov + ((size_t)s * TRI) * N + i;
+      const double* src = staged ? rec(s) : P.cov + ((size_t)s * TRI) * N + i;
+      const size_t es = staged ? 1 : N;
 #pragma unroll 4
       for (int e = tid; e < TRI; e += nth, tw.advance(nth)) {
-        const double v = src[(size_t)e * N] * (pj_[tw.a] * pj_[tw.b]);
+        const double v = src[(size_t)e * es] * (pj_[tw.a] * pj_[tw.b]);
         X[tw.a * DP + tw.b] = v;
         X[tw.b * DP + tw.a] = v;
       }
@@ -306,17 +337,21 @@ __device__ inline void smooth_mfma_traj(const SmoothParams& P, long i, double* _
     // Sigma^s = P^-1 (X + G M G') P^-1: the record (packed lower triangle) and the carried full matrix
     {
       TriWalk tw(tid);
-      double* dst = P.scov + ((size_t)s * TRI) * N + i;
+      double* dst = staged ? rec(s) : P.scov + ((size_t)s * TRI) * N + i;
+      const size_t es = staged ? 1 : N;
 #pragma unroll 4
       for (int e = tid; e < TRI; e += nth, tw.advance(nth)) {
         const double v = (X[tw.a * DP + tw.b] + BM[tw.a * DP + tw.b]) * (pij_[tw.a] * pij_[tw.b]);
-        dst[(size_t)e * N] = v;
+        dst[(size_t)e * es] = v;
         SG[tw.a * DP + tw.b] = v;
         SG[tw.b * DP + tw.a] = v;
       }
     }
     __syncthreads();
     ODEF_STAMP(8);  // pack + store
+  }
+  if (staged) {
+    for (int k = tid; k < D; k += nth) ws[W::MSV + k] = ms_[k];
   }
   if (nan_seen) P.retcode[i] = 3;  // "NaNs after smoothing" (src/smoothing.jl:25)
 }

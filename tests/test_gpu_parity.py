@@ -391,6 +391,36 @@ def test_pleiades_mfma_kernel_against_tiles_kernel_nonuniform_grid(pkg, q, monke
         np.testing.assert_allclose(l1, l0, rtol=1e-6)
 
 
+@pytest.mark.parametrize("q", [2, 5])
+def test_pleiades_smoother_record_stage(pkg, q, monkeypatch):
+    """The D = 28 (q+1) smoother on a fixed grid reads and writes its covariance records through a trajectory-major stage
+    (csrc/record_stage.h), in as many chunks as the stage budget needs.  Only addresses change: the whole stage, a stage of
+    a few records (N = 70 is not a multiple of the 64-wide transposition tiles; several launches with the carried state in the
+    workspace) and the records in place (budget 0) must agree bit for bit (a grid with two step sizes)."""
+    vf = orc.vector_field("pleiades")
+    N, dt = 70, 2.0**-10
+    grid = np.concatenate([np.arange(8) * dt, 7 * dt + np.arange(1, 7) * dt / 2])  # 14 records
+    D = 28 * (q + 1)
+    per_rec_mb = N * ((D * (D + 1) // 2 + 15) // 16 * 16) * 8 / 2**20
+    out = {}
+    for name, mb in (("whole", None), ("chunks", str(int(np.ceil(3.2 * per_rec_mb)))), ("in place", "0")):
+        if mb is None:
+            monkeypatch.delenv("ODEF_SMOOTH_STAGE_MB", raising=False)
+        else:
+            monkeypatch.setenv("ODEF_SMOOTH_STAGE_MB", mb)
+        ctx = pkg.Context("pleiades", q, 1, N, save_everystep=True)
+        ctx.set_problem_perturbed(vf.u0, [], 0.0, 1e-3, n_perturbed=14)
+        ctx.solve_fixed(grid)
+        ctx.smooth()
+        assert (ctx.get(10) == 0).all()
+        out[name] = (ctx.get(11).copy(), ctx.get(12).copy())
+        ctx.close()
+    assert np.isfinite(out["whole"][0]).all() and np.isfinite(out["whole"][1]).all()
+    for name in ("chunks", "in place"):
+        np.testing.assert_array_equal(out[name][0], out["whole"][0], err_msg=name)
+        np.testing.assert_array_equal(out[name][1], out["whole"][1], err_msg=name)
+
+
 @pytest.mark.parametrize("kind,q", [("EK1", 2), ("EK0", 3), ("EK1", 5)])
 def test_pleiades_adaptive(pkg, kind, q):
     """The reference's default solve is adaptive: PI-controlled steps on the workgroup-per-trajectory path

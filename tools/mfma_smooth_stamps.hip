@@ -10,13 +10,17 @@
 #include <random>
 using namespace odef;
 constexpr int d = 28, q = 5, NB = 6, D = 168, TRI = D * (D + 1) / 2;
-__global__ __launch_bounds__(256, 4) void kern(const SmoothParams P, double* ws) {
+#ifndef WGS
+#define WGS 4
+#endif
+__global__ __launch_bounds__(256, WGS) void kern(const SmoothParams P, double* ws) {
   using W = MfmaSmoothWs<d, NB>;
   __shared__ double lds[W::lds_size];
   smooth_mfma_traj<d, q>(P, (long)blockIdx.x, ws + (size_t)blockIdx.x * W::size, lds);
 }
 int main(int argc, char** argv) {
   const long N = argc > 1 ? atol(argv[1]) : 512, ns = 8;
+  const bool staged = argc > 2 && argv[2][0] == 's';  // records trajectory-major (record_stage.h), as odef_smooth runs fixed grids
   std::mt19937_64 rng(3);
   std::normal_distribution<double> nd;
   // one SPD covariance (scaled like a preconditioned-then-unpreconditioned state), reused for all records
@@ -57,11 +61,20 @@ int main(int argc, char** argv) {
   hipMalloc(&sm, mean.size() * 8); hipMalloc(&sc, cov.size() * 8); hipMalloc(&rc, N * 4); hipMemset(rc, 0, N * 4);
   hipMalloc(&ws, (size_t)N * MfmaSmoothWs<d, NB>::size * 8);
   P.smean = (double*)sm; P.scov = (double*)sc; P.retcode = (int*)rc;
+  if (staged) {  // every record holds the same covariance: fill the stage directly
+    const long ld = (TRI + 15) / 16 * 16;
+    std::vector<double> st((size_t)(ns - 1) * N * ld, 0.0);
+    for (size_t r = 0; r < (size_t)(ns - 1) * N; ++r)
+      for (int e = 0; e < TRI; ++e) st[r * ld + e] = cov1[e];
+    P.stage = (double*)dev(st.data(), st.size() * 8);
+    P.stage_s0 = 1; P.stage_ld = ld; P.s_lo = 1; P.s_hi = ns - 2; P.resume = 0;
+  }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 2; ++rep) {
     unsigned long long z[16] = {0};
     hipMemcpyToSymbol(HIP_SYMBOL(g_mfma_stamps), z, sizeof z);
     hipEventRecord(e0);
+    if (staged) hipMemcpy(P.stage, P.stage, 0, hipMemcpyDeviceToDevice);
     kern<<<(unsigned)N, 256>>>(P, (double*)ws);
     hipEventRecord(e1);
     if (hipEventSynchronize(e1) != hipSuccess) { printf("kernel failed\n"); return 1; }
