@@ -325,8 +325,10 @@ struct LaunchTeamFilter {
   }
 };
 // The same pass on the matrix cores (smooth_mfma.h): 4 wavefronts per trajectory, matrices in a global workspace.
+// Four workgroups per CU (128 registers): the phases are bound by the latency and traffic of the global workspace, and more
+// resident workgroups hide more of it -- 319 / 307 / 273 ms with 2 / 3 / 4 (2 048 trajectories x 64 steps).
 template <int d, int q>
-__global__ __launch_bounds__(kTeamBig, 2) void rts_smooth_mfma_kernel(const SmoothParams P, double* ws) {  // two workgroups per CU: the phases are latency-bound
+__global__ __launch_bounds__(kTeamBig, 4) void rts_smooth_mfma_kernel(const SmoothParams P, double* ws) {
   using W = MfmaSmoothWs<d, q + 1>;
   __shared__ double lds[W::lds_size];
   const long i = team_traj(P.N);

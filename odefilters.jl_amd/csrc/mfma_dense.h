@@ -35,10 +35,32 @@ constexpr int kAtbRows = ODEF_MFMA_ATB_ROWS;  // block rows per accumulator tile
 
 __device__ __attribute__((always_inline)) inline int lane64() { return (int)(threadIdx.x & 63u); }
 
+// Tile and fragment accesses are BUFFER loads / stores: a matrix is a uniform base pointer (four scalar registers as a
+// buffer resource), the lane's place in a tile one 32-bit offset register per leading dimension, the tile origin a scalar
+// offset -- `buffer_load_dwordx2 v, v_off, s[rsrc], s_tile offen`.  Written as plain pointer arithmetic the compiler keeps
+// a 64-bit address pair per access in vector registers (and spills them once a wavefront holds a tile column).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __attribute__((always_inline)) inline __amdgpu_buffer_rsrc_t mat_rsrc(const double* P) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)P, (short)0, 0x7fffffff, 0x00020000);
+}
+__device__ __attribute__((always_inline)) inline double ld8(const double* P, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(mat_rsrc(P), voff, soff, 0));
+}
+__device__ __attribute__((always_inline)) inline void st8(double* P, unsigned voff, unsigned soff, double x) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), mat_rsrc(P), voff, soff, 0);
+}
+__device__ __attribute__((always_inline)) inline unsigned lane_rc(int ld) {  // byte offset of (l / 16, l % 16)
+  const unsigned l = threadIdx.x & 63u;
+  return ((l >> 4) * (unsigned)ld + (l & 15u)) * 8u;
+}
+__device__ __attribute__((always_inline)) inline unsigned lane_cr(int ld) {  // byte offset of (l % 16, l / 16)
+  const unsigned l = threadIdx.x & 63u;
+  return ((l & 15u) * (unsigned)ld + (l >> 4)) * 8u;
+}
+__device__ __attribute__((always_inline)) inline unsigned tile_off(int ld, int r0, int c0) { return ((unsigned)r0 * (unsigned)ld + (unsigned)c0) * 8u; }
 // fragment of a k-major row-major operand: rows k0 .. k0+3, columns c0 .. c0+15
 __device__ __attribute__((always_inline)) inline double frag(const double* __restrict__ P, int ld, int k0, int c0) {
-  const int l = lane64();
-  return P[(size_t)(k0 + (l >> 4)) * ld + c0 + (l & 15)];
+  return ld8(P, lane_rc(ld), tile_off(ld, k0, c0));
 }
 __device__ __attribute__((always_inline)) inline d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -47,22 +69,22 @@ __device__ __attribute__((always_inline)) inline d4 zero4() { return d4{0.0, 0.0
 
 // tile (D layout) <-> row-major memory: element (4 v + l / 16, l % 16) at P[(r0 + 4 v + l / 16) * ld + c0 + l % 16]
 __device__ __attribute__((always_inline)) inline d4 load_tile(const double* __restrict__ P, int ld, int r0, int c0) {
-  const int l = lane64();
+  const unsigned o = lane_rc(ld);
   d4 t;
 #pragma unroll
-  for (int v = 0; v < 4; ++v) t[v] = P[(size_t)(r0 + 4 * v + (l >> 4)) * ld + c0 + (l & 15)];
+  for (int v = 0; v < 4; ++v) t[v] = ld8(P, o, tile_off(ld, r0 + 4 * v, c0));
   return t;
 }
 __device__ __attribute__((always_inline)) inline void store_tile(double* __restrict__ P, int ld, int r0, int c0, d4 t) {
-  const int l = lane64();
+  const unsigned o = lane_rc(ld);
 #pragma unroll
-  for (int v = 0; v < 4; ++v) P[(size_t)(r0 + 4 * v + (l >> 4)) * ld + c0 + (l & 15)] = t[v];
+  for (int v = 0; v < 4; ++v) st8(P, o, tile_off(ld, r0 + 4 * v, c0), t[v]);
 }
 // the transposed tile: element (i, j) of t goes to P[(r0 + j) * ld + c0 + i]
 __device__ __attribute__((always_inline)) inline void store_tile_t(double* __restrict__ P, int ld, int r0, int c0, d4 t) {
-  const int l = lane64();
+  const unsigned o = lane_cr(ld);
 #pragma unroll
-  for (int v = 0; v < 4; ++v) P[(size_t)(r0 + (l & 15)) * ld + c0 + 4 * v + (l >> 4)] = t[v];
+  for (int v = 0; v < 4; ++v) st8(P, o, tile_off(ld, r0, c0 + 4 * v), t[v]);
 }
 
 // acc[i][j] += sum_{k in [k0, k1)} A[k][m0 + 16 i + .] * B[k][n0 + 16 j + .]   (k0, k1 multiples of 4); one wavefront
@@ -334,7 +356,10 @@ __device__ inline void wg_solve_upper(const double* __restrict__ Um, const doubl
 // The barriers it removes were not the cost: with two columns resident a wavefront has 22 dependent accumulator chains
 // but no registers left to keep the next k-major fragments in flight, so every 4-load group is waited for (L2 latency per
 // block pair), and the operand traffic is the same (every wavefront streams all of U / L / M per pass).  Kept for the
-// record and for a layout with fewer, wider wavefronts; not used by default.
+// record and for a layout with fewer, wider wavefronts; not used by default.  (One column per wavefront and pass, small
+// enough for four workgroups per CU, was slower still: 483 against 356 us per sweep pair -- every wavefront then streams
+// all of U and L once per COLUMN, 2.7 MB per step, where the left-looking form shares each tile between the four
+// wavefronts of the block row through the L1.)
 template <int DPB>
 struct ColPass {
   static constexpr int kPasses = (DPB + 7) / 8;
@@ -408,44 +433,6 @@ __device__ inline void wg_solve_upper_rr(const double* __restrict__ Um, const do
       store_tile(Yt, ld, j * kB, c0, acc[j][0]);
       if (nc > 1) store_tile(Yt, ld, j * kB, c1, acc[j][1]);
     }
-  }
-}
-
-// The same with ONE tile column per wavefront and pass (DPB tiles = 8 DPB registers): small enough for four workgroups
-// per CU (128 registers), so the dependent chain of a column -- apply W_j, update the DPB - 1 - j tiles below -- is hidden
-// by the other wavefronts of the SIMD instead of by loads in flight.  Columns go round-robin over the wavefronts.
-template <int DPB>
-__device__ inline void wg_solve_upper_col(const double* __restrict__ Um, const double* __restrict__ Lm, double* __restrict__ Yt, int ld,
-                                          const double* __restrict__ lds) {
-  using LL = CholLds<DPB>;
-  const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6);
-  for (int cb = wave; cb < DPB; cb += nwaves) {
-    const int c0 = cb * kB;
-    d4 acc[DPB];
-#pragma unroll
-    for (int j = 0; j < DPB; ++j) acc[j] = load_tile(Yt, ld, j * kB, c0);
-    static_for<0, DPB>([&](auto jc) {  // forward: Z_j = W_j acc_j, acc_j' -= U[j, j']' Z_j for j' > j
-      constexpr int j = decltype(jc)::value;
-      const d4 z = apply_w<false>(lds + LL::w + j * kB * kB, acc[j]);
-      acc[j] = z;
-      static_for<j + 1, DPB>([&](auto jpc) {
-        constexpr int jp = decltype(jpc)::value;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc[jp] = mfma(-frag(Um, ld, j * kB + 4 * ks, jp * kB), z[ks], acc[jp]);
-      });
-    });
-    static_for<0, DPB>([&](auto jc) {  // backward: Gt_j = W_j' acc_j, acc_j' -= U[j', j] Gt_j for j' < j (k-major in L = U')
-      constexpr int j = DPB - 1 - decltype(jc)::value;
-      const d4 g = apply_w<true>(lds + LL::w + j * kB * kB, acc[j]);
-      acc[j] = g;
-      static_for<0, j>([&](auto jpc) {
-        constexpr int jp = decltype(jpc)::value;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc[jp] = mfma(-frag(Lm, ld, j * kB + 4 * ks, jp * kB), g[ks], acc[jp]);
-      });
-    });
-#pragma unroll
-    for (int j = 0; j < DPB; ++j) store_tile(Yt, ld, j * kB, c0, acc[j]);
   }
 }
 

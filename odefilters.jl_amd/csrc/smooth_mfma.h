@@ -70,6 +70,14 @@ struct TriWalk {
   }
 };
 
+// next tile (tr, tc), tc <= tr, of the lower triangle in row order
+__device__ inline void tri_next(int& tr, int& tc) {
+  if (++tc > tr) {
+    tc = 0;
+    ++tr;
+  }
+}
+
 // ---- the two halves of one RTS step on the workspace (shared by the smoother loop and the dense output, dense_mfma.h).
 // In:  X = P Sigma P (full symmetric, preconditioned filter covariance), mf_ = P m, SG = Sigma^s_+ (un-preconditioned, full),
 //      ms_ = m^s_+ (un-preconditioned), pj_ / pij_ = diag of P / P^-1 per state component.
@@ -177,10 +185,7 @@ __device__ inline bool mfma_gain_phase(double* __restrict__ ws, double* __restri
   // B = U'U, Gt = B^-1 Yt (the gain G = X A' (Sigma^-)^-1, src/smoothing.jl:42-43, transposed)
   mf::wg_cholesky_upper<DPB>(BM, LM, DP, lds);
   ODEF_STAMP(3);  // Cholesky
-#if defined(ODEF_SMOOTH_COL)
-  mf::wg_solve_upper_col<DPB>(BM, LM, YT, DP, lds);
-  __syncthreads();
-#elif !defined(ODEF_SMOOTH_RR)
+#ifndef ODEF_SMOOTH_RR
   mf::wg_solve_upper<DPB>(BM, LM, YT, DP, lds);  // left-looking: 22 block steps, a barrier after each
 #else  // A/B build: right-hand sides resident in the accumulators, no barrier inside -- measured 1.5x SLOWER (see mfma_dense.h)
   mf::wg_solve_upper_rr<DPB>(BM, LM, YT, DP, lds);
@@ -317,13 +322,32 @@ __device__ inline void smooth_mfma_traj(const SmoothParams& P, long i, double* _
     const double sigma2 = P.diff[(size_t)(s + 1) * N + i];
     __syncthreads();
     // X = P Sigma_i P (src/smoothing.jl:23), m~ = P m_i
-    {
+    if (staged) {
+      // by 16 x 16 tiles of the lower triangle: a tile row is 128 contiguous bytes of the record, and the mirrored tile
+      // goes out as 32-byte pieces that complete their lines within four stores (element by element the mirror image
+      // was 14 196 scattered 8-byte writes per step)
+      const double* src = rec(s);
+      const int wave = tid >> 6, nw = nth >> 6, li = (tid & 63) >> 4, lj = tid & 15;
+      int tr = 0, tc = 0;
+      for (int t = 0; t < wave; ++t) tri_next(tr, tc);
+      for (int t = wave; t < DPB * (DPB + 1) / 2; t += nw) {
+        mf::d4 x;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int a = tr * 16 + 4 * v + li, b = tc * 16 + lj;
+          const int hi = a > b ? a : b, lo = a > b ? b : a;  // (a diagonal tile is read as the full symmetric block)
+          x[v] = hi < D ? src[hi * (hi + 1) / 2 + lo] * (pj_[a] * pj_[b]) : 0.0;
+        }
+        mf::store_tile(X, DP, tr * 16, tc * 16, x);
+        if (tr != tc) mf::store_tile_t(X, DP, tc * 16, tr * 16, x);
+        for (int k = 0; k < nw; ++k) tri_next(tr, tc);
+      }
+    } else {
       TriWalk tw(tid);
-      const double* src = staged ? rec(s) : P.cov + ((size_t)s * TRI) * N + i;
-      const size_t es = staged ? 1 : N;
+      const double* src = P.cov + ((size_t)s * TRI) * N + i;
 #pragma unroll 4
       for (int e = tid; e < TRI; e += nth, tw.advance(nth)) {
-        const double v = src[(size_t)e * es] * (pj_[tw.a] * pj_[tw.b]);
+        const double v = src[(size_t)e * N] * (pj_[tw.a] * pj_[tw.b]);
         X[tw.a * DP + tw.b] = v;
         X[tw.b * DP + tw.a] = v;
       }
@@ -335,14 +359,42 @@ __device__ inline void smooth_mfma_traj(const SmoothParams& P, long i, double* _
     nan_seen = mfma_gain_phase<d, q>(ws, lds) || nan_seen;
     for (int k = tid; k < D; k += nth) P.smean[((size_t)s * D + k) * N + i] = ms_[k];
     // Sigma^s = P^-1 (X + G M G') P^-1: the record (packed lower triangle) and the carried full matrix
-    {
+    if (staged) {  // by tiles, as the unpacking above; the lower triangle of the sum is what both halves of SG get
+      double* dst = rec(s);
+      const int wave = tid >> 6, nw = nth >> 6, li = (tid & 63) >> 4, lj = tid & 15;
+      int tr = 0, tc = 0;
+      for (int t = 0; t < wave; ++t) tri_next(tr, tc);
+      for (int t = wave; t < DPB * (DPB + 1) / 2; t += nw) {
+        const mf::d4 x = mf::load_tile(X, DP, tr * 16, tc * 16), r = mf::load_tile(BM, DP, tr * 16, tc * 16);
+        mf::d4 o;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int a = tr * 16 + 4 * v + li, b = tc * 16 + lj;
+          o[v] = (x[v] + r[v]) * (pij_[a] * pij_[b]);
+          if (a < D && b <= a) dst[a * (a + 1) / 2 + b] = o[v];
+        }
+        if (tr != tc) {
+          mf::store_tile(SG, DP, tr * 16, tc * 16, o);
+          mf::store_tile_t(SG, DP, tc * 16, tr * 16, o);
+        } else {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int a = tr * 16 + 4 * v + li, b = tc * 16 + lj;
+            if (b <= a) {
+              SG[a * DP + b] = o[v];
+              SG[b * DP + a] = o[v];
+            }
+          }
+        }
+        for (int k = 0; k < nw; ++k) tri_next(tr, tc);
+      }
+    } else {
       TriWalk tw(tid);
-      double* dst = staged ? rec(s) : P.scov + ((size_t)s * TRI) * N + i;
-      const size_t es = staged ? 1 : N;
+      double* dst = P.scov + ((size_t)s * TRI) * N + i;
 #pragma unroll 4
       for (int e = tid; e < TRI; e += nth, tw.advance(nth)) {
         const double v = (X[tw.a * DP + tw.b] + BM[tw.a * DP + tw.b]) * (pij_[tw.a] * pij_[tw.b]);
-        dst[(size_t)e * es] = v;
+        dst[(size_t)e * N] = v;
         SG[tw.a * DP + tw.b] = v;
         SG[tw.b * DP + tw.a] = v;
       }
