@@ -188,10 +188,10 @@ int ensure_ws(odef_ctx* c, size_t doubles) {
   return 0;
 }
 
-// Stage for the workgroup-per-trajectory smoother: as many records as fit in `ODEF_SMOOTH_STAGE_MB` (default: a third of
-// the free device memory), at most the n_save - 1 the pass touches.  Returns the capacity in doubles (0: run in place).
-size_t ensure_stage(odef_ctx* c, long n_save, size_t per_rec_doubles) {
-  if (n_save < 3) return 0;
+// Stage for the covariance records of the workgroup-per-trajectory kernels: as many records as fit in `ODEF_SMOOTH_STAGE_MB`
+// (default: a third of the free device memory), at most `want_recs`.  Returns the capacity in doubles (0: work in place).
+size_t ensure_stage(odef_ctx* c, long want_recs, size_t per_rec_doubles) {
+  if (want_recs < 2) return 0;
   size_t budget;
   if (const char* e = getenv("ODEF_SMOOTH_STAGE_MB")) {
     budget = (size_t)atol(e) << 20;
@@ -201,7 +201,7 @@ size_t ensure_stage(odef_ctx* c, long n_save, size_t per_rec_doubles) {
     budget = (free_b + c->stage_cap * sizeof(double)) / 3;
   }
   size_t recs = budget / (per_rec_doubles * sizeof(double));
-  if (recs > (size_t)(n_save - 1)) recs = (size_t)(n_save - 1);
+  if (recs > (size_t)want_recs) recs = (size_t)want_recs;
   if (recs < 2) return 0;
   const size_t doubles = recs * per_rec_doubles;
   if (c->stage_cap < doubles) {
@@ -597,8 +597,14 @@ int odef_solve_fixed(odef_ctx* c, const double* tgrid, int64_t n_t) {
       HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
       rc = launch_filter_pleiades(c->q, c->cfg.alg == ODEF_EK1, TP, c->stream);
     } else {
+      size_t have = 0;
+      if (P.everystep) {  // the matrix-core kernel writes its records through the trajectory-major stage when all of them fit
+        const size_t tri = (size_t)c->D * (c->D + 1) / 2, per_rec = (size_t)P.N * ((tri + 15) / 16 * 16);
+        have = ensure_stage(c, nsteps + 1, per_rec);
+        if (have < (size_t)(nsteps + 1) * per_rec) have = 0;
+      }
       HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-      rc = launch_filter_pleiades_tiles(c->q, c->cfg.alg == ODEF_EK1, P, c->stream);
+      rc = launch_filter_pleiades_tiles(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 0, have ? c->d_stage : nullptr, have);
     }
   } else {
     // one lane per trajectory: the per-field buffer descriptors carry 32-bit sizes
@@ -694,7 +700,7 @@ int odef_smooth(odef_ctx* c) {
     rc = -4;
     if (!S.adaptive) {  // fixed grid: records through the trajectory-major stage, in chunks (record_stage.h)
       const size_t tri = (size_t)c->D * (c->D + 1) / 2;
-      const size_t have = ensure_stage(c, S.n_save, (size_t)S.N * ((tri + 15) / 16 * 16));
+      const size_t have = S.n_save < 3 ? 0 : ensure_stage(c, S.n_save - 1, (size_t)S.N * ((tri + 15) / 16 * 16));
       if (have) rc = launch_smooth_d28_staged(c->q, S, c->d_ws, c->d_stage, have, c->stream);
     }
     if (rc == -4) rc = launch_smooth_d28(c->q, S, c->d_ws, c->stream);

@@ -43,6 +43,10 @@ struct FilterParams {
   int* njac;
   int* nsaved;
   int* retcode;
+  // workgroup-per-trajectory matrix-core filter only (filter_mfma.h), every step saved: covariance records written
+  // trajectory-major into this stage (record_stage.h) and moved to `cov` by the host afterwards; null: written in place
+  double* cov_stage;  // [n_save][N][stage_ld]
+  long stage_ld;
 };
 
 // Row store: `base` is a wave-uniform pointer to element [field row 0][first trajectory of the

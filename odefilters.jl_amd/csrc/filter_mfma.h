@@ -913,6 +913,11 @@ struct MfmaFilter {
     const size_t N = (size_t)P.N;
     if (tid < D) P.mean[((size_t)slot * D + tid) * N + i] = m[tid];
     if constexpr (!HELPER) {
+      // in place the elements of a record lie N doubles apart (8 useful bytes per line written); staged, the record is one
+      // contiguous run that this workgroup completes line by line within the save
+      const bool staged = P.cov_stage != nullptr;
+      double* rec = staged ? P.cov_stage + ((size_t)slot * N + (size_t)i) * (size_t)P.stage_ld : P.cov + (size_t)slot * TRI * N + i;
+      const size_t es = staged ? 1 : N;
       static_for<0, NS>([&](auto sc_) {
         constexpr int s = decltype(sc_)::value;
         if (s < S.n) {
@@ -920,7 +925,7 @@ struct MfmaFilter {
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const int a = Q * TR + 4 * v + G.g, b = Pc * TR + G.j;  // row <= column in the kept triangle
-            if (G.ok[v] && a <= b) P.cov[((size_t)slot * TRI + tri(b, a)) * N + i] = T[s][v];
+            if (G.ok[v] && a <= b) rec[(size_t)tri(b, a) * es] = T[s][v];
           }
         }
       });

@@ -11,7 +11,7 @@ int launch_filter_pleiades_tiles_q2(int ek1, const FilterParams& P, hipStream_t 
 int launch_filter_pleiades_tiles_q3(int ek1, const FilterParams& P, hipStream_t s, int adaptive);
 int launch_filter_pleiades_tiles_q4(int ek1, const FilterParams& P, hipStream_t s, int adaptive);
 int launch_filter_pleiades_tiles_q5(int ek1, const FilterParams& P, hipStream_t s, int adaptive);
-int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive) {
+static int launch_filter_pleiades_tiles_order(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive) {
   switch (q) {
     case 1: return launch_filter_pleiades_tiles_q1(ek1, P, s, adaptive);
     case 2: return launch_filter_pleiades_tiles_q2(ek1, P, s, adaptive);
@@ -20,6 +20,32 @@ int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStrea
     case 5: return launch_filter_pleiades_tiles_q5(ek1, P, s, adaptive);
     default: return -2;
   }
+}
+// grid.z of the staging kernels counts records: at most 65 535 per launch
+static void launch_stage_copy(bool in, const double* src, double* dst, long N, long TRI, long ld, long n_rec, hipStream_t s) {
+  const dim3 tiles((unsigned)((N + kStageTile - 1) / kStageTile), (unsigned)((TRI + kStageTile - 1) / kStageTile));
+  for (long r0 = 0; r0 < n_rec; r0 += 65535) {
+    const unsigned nz = (unsigned)(n_rec - r0 < 65535 ? n_rec - r0 : 65535);
+    const size_t so = (size_t)r0 * (size_t)N * (size_t)(in ? TRI : ld), dof = (size_t)r0 * (size_t)N * (size_t)(in ? ld : TRI);
+    if (in)
+      hipLaunchKernelGGL(stage_in_kernel<kStageTile>, dim3(tiles.x, tiles.y, nz), dim3(256), 0, s, src + so, dst + dof, N, TRI, ld);
+    else
+      hipLaunchKernelGGL(stage_out_kernel<kStageTile>, dim3(tiles.x, tiles.y, nz), dim3(256), 0, s, src + so, dst + dof, N, TRI, ld);
+  }
+}
+// Fixed grid on the matrix-core kernel with every step saved: when `stage` holds all nsteps + 1 records the kernel writes
+// its covariance records there (trajectory-major, whole lines) and one transposition pass moves them to P.cov.
+int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles) {
+  const long D = 28L * (q + 1), TRI = D * (D + 1) / 2, ld = stage_record_ld(TRI), n_rec = P.nsteps + 1;
+  if (adaptive || !P.everystep || pleiades_filter_tiles() || !stage || (size_t)n_rec * (size_t)P.N * (size_t)ld > stage_doubles)
+    return launch_filter_pleiades_tiles_order(q, ek1, P, s, adaptive);
+  FilterParams PS = P;
+  PS.cov_stage = stage;
+  PS.stage_ld = ld;
+  const int rc = launch_filter_pleiades_tiles_order(q, ek1, PS, s, 0);
+  if (rc) return rc;
+  launch_stage_copy(false, stage, P.cov, P.N, TRI, ld, n_rec, s);
+  return 0;
 }
 int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s) {
   LaunchTeamSmooth f{P, ws, s};
@@ -40,7 +66,6 @@ int launch_smooth_d28_staged(int q, const SmoothParams& P0, double* ws, double* 
   if (hipMemcpyAsync(P0.scov + (size_t)(n - 1) * TRI * N, P0.cov + (size_t)(n - 1) * TRI * N, rec_bytes, hipMemcpyDeviceToDevice, s) !=
       hipSuccess)
     return -5;
-  const dim3 tiles((unsigned)((N + kStageTile - 1) / kStageTile), (unsigned)((TRI + kStageTile - 1) / kStageTile));
   long top = n - 2;  // highest record still to smooth
   bool first = true;
   while (top >= 1) {
@@ -53,13 +78,11 @@ int launch_smooth_d28_staged(int q, const SmoothParams& P0, double* ws, double* 
     P.s_lo = lo;
     P.s_hi = top;
     P.resume = first ? 0 : 1;
-    hipLaunchKernelGGL(stage_in_kernel<kStageTile>, dim3(tiles.x, tiles.y, (unsigned)(hi - lo + 1)), dim3(256), 0, s, P0.cov + (size_t)lo * TRI * N, stage, N,
-                       TRI, ld);
+    launch_stage_copy(true, P0.cov + (size_t)lo * TRI * N, stage, N, TRI, ld, hi - lo + 1, s);
     LaunchTeamSmooth f{P, ws, s};
     const int rc = dispatch_smooth_order<28>(q, f);
     if (rc) return rc;
-    hipLaunchKernelGGL(stage_out_kernel<kStageTile>, dim3(tiles.x, tiles.y, (unsigned)(top - lo + 1)), dim3(256), 0, s, stage, P0.scov + (size_t)lo * TRI * N, N,
-                       TRI, ld);
+    launch_stage_copy(false, stage, P0.scov + (size_t)lo * TRI * N, N, TRI, ld, top - lo + 1, s);
     top = lo - 1;
     first = false;
   }

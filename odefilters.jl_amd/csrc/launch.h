@@ -26,7 +26,8 @@ int launch_sample_d2(int q, const SampleParams& P, hipStream_t s);
 int launch_sample_d3(int q, const SampleParams& P, hipStream_t s);
 // workgroup-per-trajectory path (Pleiades, d = 28)
 int launch_filter_pleiades(int q, int ek1, const TeamFilterParams& TP, hipStream_t s);        // global-workspace team kernel
-int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive = 0);  // register-tiled kernel (default)
+int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive = 0, double* stage = nullptr,
+                                 size_t stage_doubles = 0);  // register-tiled kernel (default)
 int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s);
 int launch_smooth_d28_staged(int q, const SmoothParams& P, double* ws, double* stage, size_t stage_doubles, hipStream_t s);
 int launch_dense_d28(int q, const DenseParams& P, double* ws, hipStream_t s);  // ws: dense_d28_grid(N n_q) x team_smooth_ws_doubles

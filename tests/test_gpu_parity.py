@@ -413,12 +413,15 @@ def test_pleiades_smoother_record_stage(pkg, q, monkeypatch):
         ctx.solve_fixed(grid)
         ctx.smooth()
         assert (ctx.get(10) == 0).all()
-        out[name] = (ctx.get(11).copy(), ctx.get(12).copy())
+        out[name] = (ctx.get(11).copy(), ctx.get(12).copy(), ctx.get(0).copy(), ctx.get(1).copy())
         ctx.close()
     assert np.isfinite(out["whole"][0]).all() and np.isfinite(out["whole"][1]).all()
     for name in ("chunks", "in place"):
         np.testing.assert_array_equal(out[name][0], out["whole"][0], err_msg=name)
         np.testing.assert_array_equal(out[name][1], out["whole"][1], err_msg=name)
+        # the filter in front of it writes its records through the same stage when all of them fit ("whole" only)
+        np.testing.assert_array_equal(out[name][2], out["whole"][2], err_msg=name)
+        np.testing.assert_array_equal(out[name][3], out["whole"][3], err_msg=name)
 
 
 @pytest.mark.parametrize("kind,q", [("EK1", 2), ("EK0", 3), ("EK1", 5)])
