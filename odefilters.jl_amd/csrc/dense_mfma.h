@@ -11,7 +11,7 @@
 namespace odef {
 
 template <int d, int q>
-__device__ inline void dense_mfma_item(const DenseParams& P, long i, long jq, double* __restrict__ ws, double* __restrict__ lds) {
+__device__ __attribute__((always_inline)) inline void dense_mfma_item(const DenseParams& P, long i, long jq, double* __restrict__ ws, double* __restrict__ lds) {
   constexpr int NB = q + 1;
   using W = MfmaSmoothWs<d, NB>;
   constexpr int D = W::D, DP = W::DP, TRI = D * (D + 1) / 2;

@@ -17,6 +17,11 @@
 //   U'U G' = Y'  two block sweeps of the same shape (the backward one reads L = U' k-major, kept beside U)
 //   G M G'       two products with M symmetric
 //
+// EVERY function here is force-inlined.  Left to the inliner, the large ones (the gain phase, the Cholesky) became real
+// device functions shared by kernels with different register budgets (the smoother at four workgroups per CU = 128
+// registers, dense output and sampling at 256): a callee compiled for the wider budget then runs inside a wavefront that
+// was allocated the narrower one -- a memory access fault at address 0 on the GPU, nothing at compile time.
+//
 // Matrices are padded to DP = 16 * ceil(D / 16) with zeros (the padding block of a matrix to be factorised gets a unit
 // diagonal), so no fragment load or store is ever masked.
 #pragma once
@@ -123,9 +128,28 @@ __device__ __attribute__((always_inline)) inline void wave_atb_cols(const double
   }
 }
 
+// two block rows (m0, m1) against the same NT column tiles: every B fragment feeds two products
+template <int NT>
+__device__ __attribute__((always_inline)) inline void wave_atb_cols2(const double* __restrict__ A, int lda, int m0, int m1,
+                                                                     const double* __restrict__ B, int ldb, const int (&n0)[NT],
+                                                                     int k0, int k1, d4 (&acc0)[NT], d4 (&acc1)[NT]) {
+#pragma unroll 4
+  for (int k = k0; k < k1; k += 4) {
+    const double a0 = frag(A, lda, k, m0), a1 = frag(A, lda, k, m1);
+    double b[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[t] = frag(B, ldb, k, n0[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc0[t] = mfma(a0, b[t], acc0[t]);
+      acc1[t] = mfma(a1, b[t], acc1[t]);
+    }
+  }
+}
+
 // One MB x NB block tile of  C = [Cin -] A'B  (K = kdim rows of A and B), computed and stored by one wavefront.
 template <int MB, int NB, bool SUB>
-__device__ inline void wave_atb_store(const double* __restrict__ A, int lda, int m0, const double* __restrict__ B, int ldb, int n0,
+__device__ __attribute__((always_inline)) inline void wave_atb_store(const double* __restrict__ A, int lda, int m0, const double* __restrict__ B, int ldb, int n0,
                                       int kdim, const double* __restrict__ Cin, double* __restrict__ C, int ldc) {
   d4 acc[MB][NB];
 #pragma unroll
@@ -143,7 +167,7 @@ __device__ inline void wave_atb_store(const double* __restrict__ A, int lda, int
     }
 }
 template <int NB, bool SUB>
-__device__ inline void wave_atb_rows(int mb, const double* __restrict__ A, int lda, int m0, const double* __restrict__ B, int ldb,
+__device__ __attribute__((always_inline)) inline void wave_atb_rows(int mb, const double* __restrict__ A, int lda, int m0, const double* __restrict__ B, int ldb,
                                      int n0, int kdim, const double* __restrict__ Cin, double* __restrict__ C, int ldc) {
   if (mb == 3) wave_atb_store<3, NB, SUB>(A, lda, m0, B, ldb, n0, kdim, Cin, C, ldc);
   else if (mb == 2) wave_atb_store<2, NB, SUB>(A, lda, m0, B, ldb, n0, kdim, Cin, C, ldc);
@@ -154,7 +178,7 @@ __device__ inline void wave_atb_rows(int mb, const double* __restrict__ A, int l
 // tiles per wavefront; per k-step 6 fragment loads feed 9 MFMAs; small enough for two workgroups per CU).  No two wavefronts touch the same block, so Cin may
 // alias C.
 template <bool SUB>
-__device__ inline void wg_atb(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, int kdim,
+__device__ __attribute__((always_inline)) inline void wg_atb(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, int kdim,
                               const double* __restrict__ Cin, double* __restrict__ C, int ldc, int ib0, int ib1, int jb0, int jb1) {
   const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6);
   int strip = 0;
@@ -175,7 +199,7 @@ __device__ inline void wg_atb(const double* __restrict__ A, int lda, const doubl
 // row-major; skipped when null), `w` [16][16] = W = L^-1 (lower).  Row-lane Cholesky on the first 16 lanes with DPP broadcasts (the other
 // 48 lanes of the wavefront repeat it on the same data), then the rows of W = L^-1 by back substitution, again with DPP.
 // A non-positive pivot zeroes its column (semi-definite rule of ek_math.h); its reciprocal is taken as 0.
-__device__ inline void diag_block_factor(double* __restrict__ blk, double* __restrict__ lw, double* __restrict__ w, int ldw = kB) {
+__device__ __attribute__((always_inline)) inline void diag_block_factor(double* __restrict__ blk, double* __restrict__ lw, double* __restrict__ w, int ldw = kB) {
   const int r = tv::lane();
   double row[kB];
 #pragma unroll
@@ -247,7 +271,7 @@ struct CholLds {
 // are not touched), left-looking by block rows; Lm receives L = U' (lower, row-major) for the backward sweep.
 // A workgroup of 4 wavefronts; `lds`: CholLds<DPB>::size doubles.
 template <int DPB>
-__device__ inline void wg_cholesky_upper(double* __restrict__ Bm, double* __restrict__ Lm, int ld, double* __restrict__ lds) {
+__device__ __attribute__((always_inline)) inline void wg_cholesky_upper(double* __restrict__ Bm, double* __restrict__ Lm, int ld, double* __restrict__ lds) {
   using LL = CholLds<DPB>;
   const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6);
   constexpr int MAXT = (DPB + 3) / 4;  // tiles of a block row per wavefront (4 wavefronts)
@@ -301,7 +325,7 @@ __device__ inline void wg_cholesky_upper(double* __restrict__ Bm, double* __rest
 // Gt <- (U'U)^-1 Yt in place (DP x DP right-hand sides, row-major; U upper in Um, L = U' in Lm, the inverted diagonal
 // blocks in LDS from wg_cholesky_upper): forward sweep U' Z = Yt by block rows top-down, backward sweep U Gt = Z bottom-up.
 template <int DPB>
-__device__ inline void wg_solve_upper(const double* __restrict__ Um, const double* __restrict__ Lm, double* __restrict__ Yt, int ld,
+__device__ __attribute__((always_inline)) inline void wg_solve_upper(const double* __restrict__ Um, const double* __restrict__ Lm, double* __restrict__ Yt, int ld,
                                       const double* __restrict__ lds) {
   using LL = CholLds<DPB>;
   const int wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6);
@@ -312,34 +336,53 @@ __device__ inline void wg_solve_upper(const double* __restrict__ Um, const doubl
     const int cb = wave + s * nwaves;
     n0[s] = (cb < DPB ? cb : DPB - 1) * kB;
   }
-  for (int j = 0; j < DPB; ++j) {  // Z_j = W_j (Yt_j - sum_{k < 16 j} U[k, j]' Z[k, :])
-    const double* wj = lds + LL::w + j * kB * kB;
-    d4 acc[MAXT];
+  // Two block rows per step: the rows above (below) are streamed ONCE for both -- the re-reads of the finished rows are
+  // the traffic of a left-looking sweep (every tile of Z once per later block row: 1.2 MB per sweep at DPB = 11) -- and the
+  // second row picks up the first one's result from the accumulator registers (a D-layout tile is a K = 16 B operand).
+  for (int j = 0; j < DPB; j += 2) {  // Z_j = W_j (Yt_j - sum_{k < 16 j} U[k, j]' Z[k, :])
+    const bool two = j + 1 < DPB;
+    const int j1 = two ? j + 1 : j;
+    d4 acc0[MAXT], acc1[MAXT];
 #pragma unroll
-    for (int s = 0; s < MAXT; ++s) acc[s] = zero4();
-    wave_atb_cols<MAXT>(Um, ld, j * kB, Yt, ld, n0, 0, j * kB, acc);
+    for (int s = 0; s < MAXT; ++s) acc0[s] = acc1[s] = zero4();
+    wave_atb_cols2<MAXT>(Um, ld, j * kB, j1 * kB, Yt, ld, n0, 0, j * kB, acc0, acc1);
+    const double* w0 = lds + LL::w + j * kB * kB;
+    const double* w1 = lds + LL::w + j1 * kB * kB;
 #pragma unroll
     for (int s = 0; s < MAXT; ++s) {
       const int cb = wave + s * nwaves;
       if (cb < DPB) {
-        const d4 r = load_tile(Yt, ld, j * kB, cb * kB) - acc[s];
-        store_tile(Yt, ld, j * kB, cb * kB, apply_w<false>(wj, r));
+        const d4 z0 = apply_w<false>(w0, load_tile(Yt, ld, j * kB, cb * kB) - acc0[s]);
+        store_tile(Yt, ld, j * kB, cb * kB, z0);
+        if (two) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) acc1[s] = mfma(frag(Um, ld, j * kB + 4 * ks, j1 * kB), z0[ks], acc1[s]);
+          store_tile(Yt, ld, j1 * kB, cb * kB, apply_w<false>(w1, load_tile(Yt, ld, j1 * kB, cb * kB) - acc1[s]));
+        }
       }
     }
     __syncthreads();
   }
-  for (int j = DPB - 1; j >= 0; --j) {  // Gt_j = W_j' (Z_j - sum_{k >= 16 (j+1)} L[k, j]' Gt[k, :])
-    const double* wj = lds + LL::w + j * kB * kB;
-    d4 acc[MAXT];
+  for (int j = DPB - 1; j >= 0; j -= 2) {  // Gt_j = W_j' (Z_j - sum_{k >= 16 (j+1)} L[k, j]' Gt[k, :])
+    const bool two = j >= 1;
+    const int j1 = two ? j - 1 : j;
+    d4 acc0[MAXT], acc1[MAXT];
 #pragma unroll
-    for (int s = 0; s < MAXT; ++s) acc[s] = zero4();
-    wave_atb_cols<MAXT>(Lm, ld, j * kB, Yt, ld, n0, (j + 1) * kB, DPB * kB, acc);
+    for (int s = 0; s < MAXT; ++s) acc0[s] = acc1[s] = zero4();
+    wave_atb_cols2<MAXT>(Lm, ld, j * kB, j1 * kB, Yt, ld, n0, (j + 1) * kB, DPB * kB, acc0, acc1);
+    const double* w0 = lds + LL::w + j * kB * kB;
+    const double* w1 = lds + LL::w + j1 * kB * kB;
 #pragma unroll
     for (int s = 0; s < MAXT; ++s) {
       const int cb = wave + s * nwaves;
       if (cb < DPB) {
-        const d4 r = load_tile(Yt, ld, j * kB, cb * kB) - acc[s];
-        store_tile(Yt, ld, j * kB, cb * kB, apply_w<true>(wj, r));
+        const d4 g0 = apply_w<true>(w0, load_tile(Yt, ld, j * kB, cb * kB) - acc0[s]);
+        store_tile(Yt, ld, j * kB, cb * kB, g0);
+        if (two) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) acc1[s] = mfma(frag(Lm, ld, j * kB + 4 * ks, j1 * kB), g0[ks], acc1[s]);
+          store_tile(Yt, ld, j1 * kB, cb * kB, apply_w<true>(w1, load_tile(Yt, ld, j1 * kB, cb * kB) - acc1[s]));
+        }
       }
     }
     __syncthreads();
@@ -382,7 +425,7 @@ struct ColPass {
 // acc_j' -= U[j, j']' Z_j for j' > j), the backward sweep (Gt_j = W_j' acc_j, then acc_j' -= U[j', j] Gt_j for j' < j,
 // read k-major from L = U'), and stores them.  No barrier: 22 block steps of the left-looking form each ended in one.
 template <int DPB>
-__device__ inline void wg_solve_upper_rr(const double* __restrict__ Um, const double* __restrict__ Lm, double* __restrict__ Yt, int ld,
+__device__ __attribute__((always_inline)) inline void wg_solve_upper_rr(const double* __restrict__ Um, const double* __restrict__ Lm, double* __restrict__ Yt, int ld,
                                          const double* __restrict__ lds) {
   using LL = CholLds<DPB>;
   const int wave = (int)(threadIdx.x >> 6);
@@ -440,7 +483,7 @@ __device__ inline void wg_solve_upper_rr(const double* __restrict__ Um, const do
 // registers of their wavefront: per pass a wavefront loads its <= 2 tile columns of B once and produces the same columns
 // of C, two tile rows at a time, from k-major fragments of A.
 template <int DPB>
-__device__ inline void wg_atb_rescols(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int ld) {
+__device__ __attribute__((always_inline)) inline void wg_atb_rescols(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int ld) {
   const int wave = (int)(threadIdx.x >> 6);
   for (int pass = 0; pass < ColPass<DPB>::kPasses; ++pass) {
     const int nc = ColPass<DPB>::ncols(wave, pass);

@@ -12,7 +12,7 @@ namespace odef {
 // ms_ <- ms_ + scale L xi for the covariance C (full symmetric, un-preconditioned) in the X slot of the workspace; variates
 // c0 .. c0 + D - 1 of the stream.  X is destroyed (its padding block ends as the identity, which nothing reads).
 template <int d, int q>
-__device__ inline void mfma_draw(double scale, unsigned long long seed, unsigned long long c0, double* __restrict__ ws, double* __restrict__ lds) {
+__device__ __attribute__((always_inline)) inline void mfma_draw(double scale, unsigned long long seed, unsigned long long c0, double* __restrict__ ws, double* __restrict__ lds) {
   using W = MfmaSmoothWs<d, q + 1>;
   constexpr int D = W::D, DP = W::DP, DPB = W::DPB;
   const int tid = (int)threadIdx.x, nth = (int)blockDim.x;
@@ -39,7 +39,7 @@ __device__ inline void mfma_draw(double scale, unsigned long long seed, unsigned
 }
 
 template <int d, int q>
-__device__ inline void sample_mfma_item(const SampleParams& P, long i, long j, double* __restrict__ ws, double* __restrict__ lds) {
+__device__ __attribute__((always_inline)) inline void sample_mfma_item(const SampleParams& P, long i, long j, double* __restrict__ ws, double* __restrict__ lds) {
   constexpr int NB = q + 1;
   using W = MfmaSmoothWs<d, NB>;
   constexpr int D = W::D, DP = W::DP, TRI = D * (D + 1) / 2;

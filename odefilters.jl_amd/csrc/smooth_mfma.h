@@ -71,7 +71,7 @@ struct TriWalk {
 };
 
 // next tile (tr, tc), tc <= tr, of the lower triangle in row order
-__device__ inline void tri_next(int& tr, int& tc) {
+__device__ __attribute__((always_inline)) inline void tri_next(int& tr, int& tc) {
   if (++tc > tr) {
     tc = 0;
     ++tr;
@@ -85,7 +85,7 @@ __device__ inline void tri_next(int& tr, int& tc) {
 //                      MM = P Sigma^s_+ P - BM, dl_ = P m^s_+ - mp_
 // mfma_gain_phase:     BM = U'U, Yt <- G' = BM^-1 Yt, ms_ <- P^-1 (mf_ + G dl_), BM <- G M G'   (returns "NaN seen")
 template <int d, int q>
-__device__ inline void mfma_predict_phase(const PriorConsts& pc, double sigma2, double* __restrict__ ws, double* __restrict__ lds) {
+__device__ __attribute__((always_inline)) inline void mfma_predict_phase(const PriorConsts& pc, double sigma2, double* __restrict__ ws, double* __restrict__ lds) {
   using W = MfmaSmoothWs<d, q + 1>;
   constexpr int NB = q + 1, D = W::D, DP = W::DP, DPB = W::DPB;
   const int tid = (int)threadIdx.x, nth = (int)blockDim.x;
@@ -163,7 +163,7 @@ __device__ inline void mfma_predict_phase(const PriorConsts& pc, double sigma2, 
   ODEF_STAMP(2);  // B, M
 }
 template <int d, int q>
-__device__ inline bool mfma_gain_phase(double* __restrict__ ws, double* __restrict__ lds) {
+__device__ __attribute__((always_inline)) inline bool mfma_gain_phase(double* __restrict__ ws, double* __restrict__ lds) {
   using W = MfmaSmoothWs<d, q + 1>;
   constexpr int NB = q + 1, D = W::D, DP = W::DP, DPB = W::DPB;
   const int tid = (int)threadIdx.x, nth = (int)blockDim.x;
@@ -221,7 +221,7 @@ __device__ inline bool mfma_gain_phase(double* __restrict__ ws, double* __restri
 }
 
 template <int d, int q>
-__device__ inline void smooth_mfma_traj(const SmoothParams& P, long i, double* __restrict__ ws, double* __restrict__ lds) {
+__device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const SmoothParams& P, long i, double* __restrict__ ws, double* __restrict__ lds) {
   constexpr int NB = q + 1;
   using W = MfmaSmoothWs<d, NB>;
   constexpr int D = W::D, DP = W::DP, DPB = W::DPB, TRI = D * (D + 1) / 2;
