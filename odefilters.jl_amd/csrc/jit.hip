@@ -6,6 +6,7 @@
 // src/state_initialization.jl:2-53), plus the analytic Jacobian for EK1 (optional).  hipcc compiles the very same lane
 // functions (ek_lane.h, smooth_lane.h, dense_lane.h, sample_lane.h, smooth_rows.h) around it for gfx950; the
 // kernels are loaded with the module API and launched with the same parameter structs as the compiled-in ones.
+#include <elf.h>
 #include <hip/hip_runtime.h>
 
 #include <fcntl.h>
@@ -16,6 +17,7 @@
 #include <cerrno>
 
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <map>
 #include <memory>
@@ -145,6 +147,39 @@ std::string read_file(const std::string& path) {
   return out;
 }
 
+// Names of the device functions a code object keeps OUT OF LINE (anything of type FUNC that is not one of our kernels).
+// Such a function is compiled once, for the loosest register budget among its callers; called from a kernel with a
+// tighter one (odef_jit_smooth_rows is pinned to 128 registers) it would address registers its wavefront does not own --
+// a memory access fault at run time.  The generated kernels force-inline everything, and the build is refused otherwise.
+std::string out_of_line_device_functions(const std::string& co) {
+  const size_t at = co.find("\x7f" "ELF");
+  if (at == std::string::npos || co.size() - at < sizeof(Elf64_Ehdr)) return "";
+  const char* base = co.data() + at;
+  const size_t avail = co.size() - at;
+  Elf64_Ehdr eh;
+  std::memcpy(&eh, base, sizeof eh);
+  if (eh.e_shentsize != sizeof(Elf64_Shdr) || eh.e_shoff + (size_t)eh.e_shnum * sizeof(Elf64_Shdr) > avail) return "";
+  std::string names;
+  for (unsigned i = 0; i < eh.e_shnum; ++i) {
+    Elf64_Shdr sh;
+    std::memcpy(&sh, base + eh.e_shoff + (size_t)i * sizeof sh, sizeof sh);
+    if (sh.sh_type != SHT_SYMTAB || sh.sh_link >= eh.e_shnum || sh.sh_offset + sh.sh_size > avail) continue;
+    Elf64_Shdr st;
+    std::memcpy(&st, base + eh.e_shoff + (size_t)sh.sh_link * sizeof st, sizeof st);
+    if (st.sh_offset + st.sh_size > avail) continue;
+    for (size_t k = 0; k + sizeof(Elf64_Sym) <= sh.sh_size; k += sizeof(Elf64_Sym)) {
+      Elf64_Sym sym;
+      std::memcpy(&sym, base + sh.sh_offset + k, sizeof sym);
+      if (ELF64_ST_TYPE(sym.st_info) != STT_FUNC || sym.st_shndx == SHN_UNDEF || sym.st_name >= st.sh_size) continue;
+      const char* nm = base + st.sh_offset + sym.st_name;
+      const size_t len = strnlen(nm, st.sh_size - sym.st_name);
+      if (len >= 9 && std::strncmp(nm, "odef_jit_", 9) == 0) continue;
+      names += std::string(nm, len) + "\n";
+    }
+  }
+  return names;
+}
+
 bool compile(const std::string& src, const std::string& include_dir, std::vector<char>& code, std::string& err) {
   char tmpl[] = "/tmp/odef_jit_XXXXXX";
   const char* dir = mkdtemp(tmpl);
@@ -193,6 +228,15 @@ bool compile(const std::string& src, const std::string& include_dir, std::vector
     const std::string co = read_file(outp);
     ok = !co.empty();
     code.assign(co.begin(), co.end());
+    const std::string stray = ok ? out_of_line_device_functions(co) : std::string();
+    if (!stray.empty()) {
+      err = "odef_rhs_compile: the compiler left device functions out of line (kernels with different register budgets would share them):\n" + stray.substr(0, 4000);
+      remove(srcp.c_str());
+      remove(outp.c_str());
+      remove(logp.c_str());
+      rmdir(dir);
+      return false;
+    }
   }
   if (!ok) {
     if (!spawned) {

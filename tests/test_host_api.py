@@ -78,6 +78,13 @@ def test_user_vector_field_compiles_without_a_gpu(pkg):
         pkg.compile_rhs("WrongDim", USER_LORENZ.replace("UserLorenz", "WrongDim"), 2, 3)
     with pytest.raises(pkg.OdefError, match="d must be in 1..10"):
         pkg.compile_rhs("TooBig", USER_LORENZ.replace("UserLorenz", "TooBig"), 12, 3)
+    # a device function the compiler keeps out of line would be shared by kernels with different register budgets (a fault
+    # on the GPU, nothing at compile time): the code object is inspected and refused
+    helper = "__device__ __attribute__((noinline)) double odef_test_outlined(double x) { return 1.5 * x; }\n"
+    text = helper + USER_LORENZ.replace("UserLorenz", "Outlined").replace("const double s = p[0],", "const double s = odef_test_outlined(p[0]) / 1.5,")
+    assert text.count("odef_test_outlined(p[0])") == 2
+    with pytest.raises(pkg.OdefError, match="out of line"):
+        pkg.compile_rhs("Outlined", text, 3, 3)
 
 
 def test_fixed_time_grid_validation_and_tstops(pkg):
