@@ -293,8 +293,8 @@ __global__ __launch_bounds__(kTilesBlock) void ek_filter_tiles_adaptive_kernel(c
   else
     TF::template run_adaptive<false>(P, i, (int)threadIdx.x, sm, &st);
 }
-// ODEF_PLEIADES_FILTER=tiles selects the register-tiled VALU kernel for fixed-step solves too (default: the MFMA
-// kernel of filter_mfma.h; adaptive solves always run on the tiled kernel)
+// ODEF_PLEIADES_FILTER=tiles selects the register-tiled VALU kernels (default: the MFMA kernels of filter_mfma.h, fixed
+// grids and adaptive)
 inline bool pleiades_filter_tiles() {
   const char* e = getenv("ODEF_PLEIADES_FILTER");
   return e && e[0] == 't';
@@ -305,8 +305,11 @@ struct LaunchTilesFilter {
   int adaptive = 0;
   template <class RHS, int q, bool EK1>
   void operator()() {
-    if (!adaptive && !pleiades_filter_tiles()) {
-      hipLaunchKernelGGL((ek_filter_mfma_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kMfBlock), 0, s, P);
+    if (!pleiades_filter_tiles()) {
+      if (adaptive)
+        hipLaunchKernelGGL((ek_filter_mfma_adaptive_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kMfBlock), 0, s, P);
+      else
+        hipLaunchKernelGGL((ek_filter_mfma_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kMfBlock), 0, s, P);
       return;
     }
     if (adaptive)

@@ -933,6 +933,191 @@ struct MfmaFilter {
     if (tid == 0) P.diff[(size_t)slot * N + i] = diffusion;
   }
 
+  // Adaptive solve of trajectory i on the same step (src/perform_step.jl:27-93 with OrdinaryDiffEq's PI controller, as
+  // TilesFilter::run_adaptive does on the vector units): per attempt the controller (thread 0) fixes h and fills the
+  // preconditioner table in LDS, the helper runs the measurement chain for it (not overlapped with the previous step: h is
+  // only known now), all run `step`, the controller accepts or rejects.  A rejected attempt goes back to the previous
+  // RECORD (every attempt is saved, §3.2): the mean and the covariance tiles are re-read from it -- the step has
+  // overwritten both in place, and there is no room on chip for a second copy of 78 tiles.
+  template <bool HELPER>
+  ODEF_MF_FN void run_adaptive(const FilterParams& P, long i, int tid, double* __restrict__ sm) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (HELPER) __builtin_amdgcn_s_setprio(3);  // the helper's serial work is what the others wait for: first pick at issue and instruction fetch
+    double* m = sm + W::MV;
+    double* sc = sm + W::SC;
+    const size_t N = (size_t)P.N;
+    Geo G;
+    G.lane = tid & 63;
+    G.g = G.lane >> 4;
+    G.j = tid & 15;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int ii = 4 * v + G.g;
+      G.ok[v] = (ii < TR) && (G.j < TR);
+      G.sym[v] = (ii < G.j ? ii : G.j) * TR + (ii < G.j ? G.j : ii);
+    }
+    Slots S;
+    S.n = 0;
+    static_for<0, NS>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value;
+      int qq = 0, pp = 0;
+      static_for<0, kMfTileWaves>([&](auto wc) {
+        constexpr int w = decltype(wc)::value;
+        constexpr int cq = make_mf_own<NT>().Q[w][s], cp = make_mf_own<NT>().P[w][s], cn = make_mf_own<NT>().n[w];
+        if (!HELPER && wave == w) {
+          qq = cq < 0 ? 0 : cq;
+          pp = cp < 0 ? 0 : cp;
+          S.n = cn;
+        }
+      });
+      S.tq[s] = qq;
+      S.tp[s] = pp;
+    });
+    d4 T[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) T[s] = mf::zero4();
+    __attribute__((unused)) double pl_local[RHS::np > 0 ? RHS::np : 1];
+    const double* pl = pl_local;
+    for (int k = 0; k < RHS::np; ++k) pl_local[k] = P.p_shared ? P.p[k] : P.p[(size_t)k * N + i];
+    if constexpr (!HELPER) {
+      if (tid == 0) {  // Taylor-mode initial mean (src/state_initialization.jl), zero covariance
+        double u0[d], m0[D];
+        for (int a = 0; a < d; ++a) u0[a] = P.u0[(size_t)a * N + i];
+        taylor_init<RHS, q>(u0, pl, m0);
+        for (int k = 0; k < D; ++k) m[k] = m0[k];
+        for (int k = 0; k < 8; ++k) sc[k] = 0.0;
+        for (int a = 0; a < d; ++a) sm[W::UC + a] = u0[a];
+      }
+      if (tid < 32) sm[W::Z + tid] = 0.0;  // the entries behind z[d-1] stay zero
+    }
+    __syncthreads();
+    double* tabL = sm + W::TAB;
+    double* wd = sm + W::WD;
+    double* ucur = sm + W::UC;
+    double* ctl = sm + W::CTL;  // [0] go on, [1] restore the previous state, [2] slot of this attempt's record, [3] naccept, [4] state finite
+    save_record<HELPER>(P, i, 0, 0.0, sm, T, S, G, tid);
+    const bool boss = !HELPER && tid == 0;  // controller state: meaningful in tile thread 0 only
+    const Controller& ct = P.ctrl;
+    double t = P.t0, h = P.dt0, qold = ct.qoldinit, q11 = 1.0, sc3_prev = 0.0, sc4_prev = 0.0;
+    int naccept = 0, nreject = 0, nsaved = 1, ret = 0;
+    long attempts = 0;
+    const long max_attempts = 20 * P.max_save + 1000;
+    if (boss) P.tsave[i] = P.t0;
+    for (;;) {
+      if (boss) {
+        double go = 1.0;
+        if (!(t < P.t1)) go = 0.0;
+        else if (nsaved >= P.max_save || attempts >= max_attempts) { ret = 1; go = 0.0; }  // MaxIters
+        else {
+          ++attempts;
+          h = fmin(h, ct.dtmax);
+          h = fmin(h, P.t1 - t);  // tstop clipping
+          if (!(h > ct.dtmin)) { ret = 2; go = 0.0; }  // DtLessThanMin
+          else {
+            precond_fill<NB>(h, precond_val<q>(h), tabL);
+            sc3_prev = sc[3];
+            sc4_prev = sc[4];
+          }
+        }
+        ctl[0] = go;
+        ctl[3] = (double)naccept;
+      }
+      __syncthreads();
+      if (ctl[0] == 0.0) break;  // workgroup-uniform
+      if constexpr (HELPER) {
+        chain_a1(P.pc, pl, tabL, true, sm, G.lane);  // (the table is in place: the copy inside is onto itself)
+        chain_a2(P.pc, sm, G.lane);
+        chain_b(P.pc, true, sm, fresh(G));
+        chain_c(sm, G.lane);
+      }
+      __syncthreads();
+      step<HELPER>(P.pc, pl, tabL, nullptr, P.fixed_diffusion, (int)ctl[3], sm, T, S, G, tid, wave);
+      if (boss) {
+        // DiffEqBase.calculate_residuals! + ODE_DEFAULT_NORM (src/perform_step.jl:78-84); sc[0] = local diffusion
+        double acc = 0.0;
+        for (int r = 0; r < d; ++r) {
+          const double es = sqrt(sc[0] * wd[r]);
+          const double e = h * es / (P.abstol + fmax(fabs(ucur[r]), fabs(m[r])) * P.reltol);
+          acc += e * e;
+        }
+        double EEst = sqrt(acc / d);
+        if (!(EEst == EEst) || !(fabs(EEst) <= 1.79769313486231570815e+308)) EEst = INFINITY;
+        for (int r = 0; r < d; ++r) ucur[r] = m[r];  // integ.u .= u_filt, also when rejected (src/perform_step.jl:86)
+        double qq;
+        if (EEst == 0.0) {
+          qq = 1.0 / ct.qmax;
+        } else {
+          q11 = pow(EEst, ct.beta1);
+          qq = q11 / pow(qold, ct.beta2);
+          qq = fmax(1.0 / ct.qmax, fmin(1.0 / ct.qmin, qq / ct.gamma));
+        }
+        const bool accepted = EEst <= 1.0;  // OrdinaryDiffEq accepts on <=, the cache commits on < (:89)
+        const bool restore = !(EEst < 1.0);
+        if (restore) {
+          sc[3] = sc3_prev;
+          sc[4] = sc4_prev;
+        }
+        if (accepted) {
+          if (qq <= ct.qsteady_max && qq >= ct.qsteady_min) qq = 1.0;
+          qold = fmax(EEst, ct.qoldinit);
+          double tn = t + h;
+          if (fabs(tn - P.t1) < 100.0 * 2.220446049250313e-16 * fmax(fabs(tn), fabs(P.t1))) tn = P.t1;
+          t = tn;
+          ++naccept;
+          h = h / qq;
+        } else {
+          ++nreject;
+          h = h / fmin(1.0 / ct.qmin, q11 / ct.gamma);
+        }
+        ctl[1] = restore ? 1.0 : 0.0;
+        ctl[2] = (double)nsaved;
+        P.tsave[(size_t)nsaved * N + i] = t;
+      }
+      __syncthreads();
+      const long slot = (long)ctl[2];
+      if (ctl[1] != 0.0) {  // x_filt is not committed: back to the previous record, cache.x = P^-1 (P x) (:73)
+        if (tid < D) {
+          const double v = P.mean[((size_t)(slot - 1) * D + tid) * N + i];
+          m[tid] = tabL[kTabPIJ + tid / d] * (tabL[kTabPJ + tid / d] * v);
+        }
+        if constexpr (!HELPER) {
+          const double* rec = P.cov + (size_t)(slot - 1) * TRI * N + i;
+          static_for<0, NS>([&](auto sc_) {
+            constexpr int s = decltype(sc_)::value;
+            if (s < S.n) {
+              const int Q = S.tq[s], Pc = S.tp[s];
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                const int a = Q * TR + 4 * v + G.g, b = Pc * TR + G.j;
+                const int hi = a > b ? a : b, lo = a > b ? b : a;  // a diagonal tile holds both halves
+                T[s][v] = G.ok[v] ? rec[(size_t)tri(hi, lo) * N] : 0.0;
+              }
+            }
+          });
+        }
+      }
+      save_record<HELPER>(P, i, slot, sc[4], sm, T, S, G, tid);
+      if (boss) {
+        ++nsaved;
+        bool finite = true;
+        for (int k = 0; k < D; ++k) finite = finite && (fabs(m[k]) <= 1.79769313486231570815e+308);
+        if (!finite) ret = 3;
+        ctl[4] = finite ? 1.0 : 0.0;  // its own word: ctl[0] is rewritten by thread 0 right after the next barrier
+      }
+      __syncthreads();
+      if (ctl[4] == 0.0) break;
+    }
+    if (boss) {
+      P.loglik[i] = sc[3];
+      P.naccept[i] = naccept;
+      P.nreject[i] = nreject;
+      P.nf[i] = naccept + nreject;
+      P.njac[i] = IS_EK1 ? naccept + nreject : 0;
+      P.nsaved[i] = nsaved;
+      P.retcode[i] = ret;
+    }
+  }
+
   // whole fixed-step solve of trajectory i
   template <bool HELPER>
   ODEF_MF_FN void run(const FilterParams& P, long i, int tid, double* __restrict__ sm) {
@@ -1031,6 +1216,18 @@ __global__ __launch_bounds__(kMfBlock) void ek_filter_mfma_kernel(const FilterPa
     MF::template run<true>(P, i, (int)threadIdx.x, sm);
   else
     MF::template run<false>(P, i, (int)threadIdx.x, sm);
+}
+
+template <class RHS, int q, bool EK1>
+__global__ __launch_bounds__(kMfBlock) void ek_filter_mfma_adaptive_kernel(const FilterParams P) {
+  using MF = MfmaFilter<RHS, q, EK1>;
+  __shared__ double sm[MF::W::size];
+  const long i = team_traj(P.N);
+  if (i < 0) return;
+  if (threadIdx.x >= 64 * kMfHelper)
+    MF::template run_adaptive<true>(P, i, (int)threadIdx.x, sm);
+  else
+    MF::template run_adaptive<false>(P, i, (int)threadIdx.x, sm);
 }
 
 }  // namespace odef

@@ -446,6 +446,34 @@ def test_pleiades_adaptive(pkg, kind, q):
         assert sol.t[i, n - 1] == t1
 
 
+@pytest.mark.parametrize("kind,q", [("EK1", 3), ("EK0", 5)])
+def test_pleiades_adaptive_mfma_kernel_against_tiles_kernel(pkg, kind, q, monkeypatch):
+    """The two adaptive D = 28 (q+1) filters -- matrix cores / Joseph form (MfmaFilter::run_adaptive, default) and register
+    tiles / square-root form (TilesFilter::run_adaptive) -- under the same controller: same accepted and rejected attempts,
+    same save times to 1e-6 and solution block to 1e-7 (the tolerances of the oracle test above); a run that starts with rejections (records re-read from the previous attempt)."""
+    vf = orc.vector_field("pleiades")
+    N, t1, dt0 = 6, 0.05, 0.02
+    out = {}
+    for name, env in (("mfma", ""), ("tiles", "tiles")):
+        monkeypatch.setenv("ODEF_PLEIADES_FILTER", env)
+        ens = pkg.EnsembleProblem(pkg.ODEProblem("pleiades", vf.u0, (0.0, t1), ()), perturb_scale=1e-3, n_perturbed=14)
+        sol = pkg.solve(ens, _alg(pkg, kind, q), pkg.EnsembleHIP(), trajectories=N, adaptive=True, dt=dt0, max_steps=256,
+                        abstol=1e-8, reltol=1e-6)
+        assert sol.retcode == ["Success"] * N
+        out[name] = (np.array(sol.nsaved), np.array(sol.destats.nreject), np.array(sol.destats.naccept), sol.t.copy(),
+                     sol.x_filt_mean().copy(), sol.x_filt_cov().copy())
+    a, b = out["mfma"], out["tiles"]
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[2], b[2])
+    assert (q == 5 or (a[1] >= 1).all()) and np.isfinite(a[5]).all()
+    for i in range(N):
+        n = int(a[0][i])
+        # the step sizes come out of pow(error estimate): the two covariance forms differ in the last digits of it
+        np.testing.assert_allclose(a[3][i, :n], b[3][i, :n], rtol=1e-6)
+        np.testing.assert_allclose(a[4][i, :n, :28], b[4][i, :n, :28], rtol=1e-7, atol=1e-12)
+
+
 @pytest.mark.parametrize("model", ["fixed", "fixedMAP"])
 @pytest.mark.parametrize("adaptive", [False, True])
 def test_static_diffusion_models(pkg, model, adaptive):

@@ -81,6 +81,21 @@ if "pleiades_smooth" in args.modes.split(","):
     print(json.dumps({"mode": "pleiades_smooth", "traj": N, "nsteps": nsp, "filter_everystep_ms": f_ms, "smooth_ms": s_ms,
                       "filter_steps_per_s": N * nsp / (f_ms * 1e-3), "smoother_steps_per_s": N * (nsp - 1) / (s_ms * 1e-3)}))
     ctx.close()
+if "pleiades_adaptive" in args.modes.split(","):
+    # adaptive D = 168 solve (PI controller, every attempt a record) + smoother over the records in place
+    u0 = [3.0, 3.0, -1.0, -3.0, 2.0, -2.0, 2.0, 3.0, -3.0, 2.0, 0.0, 0.0, -4.0, 4.0,
+          0.0, 0.0, 0.0, 0.0, 0.0, 1.75, -1.5, 0.0, 0.0, 0.0, -1.25, 1.0, 0.0, 0.0]
+    ctx = pkg.Context("pleiades", 3, 1, N, smooth=True)
+    ctx.set_problem_perturbed(u0, [], 0.0, 1e-3, n_perturbed=14)
+    for _ in range(2):
+        ctx.solve_adaptive(0.25, 1e-8, 1e-6, 0.02, None, 128); ctx.smooth()
+    f_ms, s_ms = ctx.kernel_time_ms(0)[0], ctx.kernel_time_ms(1)[0]
+    att = int(ctx.get(5).sum() + ctx.get(6).sum())
+    kern = "tiles (VALU)" if os.environ.get("ODEF_PLEIADES_FILTER", "").startswith("t") else "mfma"
+    print(json.dumps({"mode": "pleiades_adaptive", "kernel": kern, "order": 3, "traj": N, "t1": 0.25, "filter_ms": f_ms, "smooth_ms": s_ms,
+                      "attempted_steps": att, "attempted_steps_per_s": att / (f_ms * 1e-3),
+                      "retcodes_ok": bool((ctx.get(10) == 0).all())}))
+    ctx.close()
 if "sample" in args.modes.split(","):
     nsp = min(ns, 256)
     ctx = pkg.Context("lorenz63", 3, 1, N, smooth=True)
