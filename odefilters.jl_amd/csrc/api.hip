@@ -698,10 +698,19 @@ int odef_smooth(odef_ctx* c) {
       rc = -3;
   else if (c->team_path) {
     rc = -4;
-    if (!S.adaptive) {  // fixed grid: records through the trajectory-major stage, in chunks (record_stage.h)
+    {  // the covariance records go through the trajectory-major stage, in blocks (record_stage.h)
+      long n_rec = S.n_save;
+      if (S.adaptive) {  // save slots in use: the largest record count of the ensemble
+        std::vector<int> ns((size_t)S.N);
+        HIPCHK(c, hipMemcpyAsync(ns.data(), S.nsaved, ns.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        n_rec = 1;
+        for (int v : ns) n_rec = v > n_rec ? v : n_rec;
+        if (n_rec > S.n_save) n_rec = S.n_save;
+      }
       const size_t tri = (size_t)c->D * (c->D + 1) / 2;
-      const size_t have = S.n_save < 3 ? 0 : ensure_stage(c, S.n_save - 1, (size_t)S.N * ((tri + 15) / 16 * 16));
-      if (have) rc = launch_smooth_d28_staged(c->q, S, c->d_ws, c->d_stage, have, c->stream);
+      const size_t have = n_rec < 3 ? 0 : ensure_stage(c, n_rec - 1, (size_t)S.N * ((tri + 15) / 16 * 16));
+      if (have) rc = launch_smooth_d28_staged(c->q, S, n_rec, c->d_ws, c->d_stage, have, c->stream);
     }
     if (rc == -4) rc = launch_smooth_d28(c->q, S, c->d_ws, c->stream);
   } else

@@ -397,8 +397,9 @@ struct SmoothParams {
   double* stage;   // [records stage_s0 ..][N][stage_ld]: filter covariances in, smoothed covariances out (in place)
   long stage_s0;   // save index of the first staged record
   long stage_ld;   // doubles per staged record (the packed triangle rounded up to whole 128-byte lines)
-  long s_lo, s_hi; // this launch smooths records s_hi, s_hi - 1, .., s_lo
-  int resume;      // 0: first launch of the pass (the carried state starts from the last record); 1: continue
+  long stage_hi;   // save index of the last staged record: this launch smooths the records stage_hi .. stage_s0 that a trajectory
+                   // has (of its 1 .. n - 2); a trajectory whose last record n - 1 lies in the stage starts its carried state
+                   // from it, one whose last record lies above continues from the workspace, one below has nothing to do yet
 };
 
 }  // namespace odef

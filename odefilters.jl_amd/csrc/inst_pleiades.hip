@@ -51,40 +51,35 @@ int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s) {
   LaunchTeamSmooth f{P, ws, s};
   return dispatch_smooth_order<28>(q, f);
 }
-// The same pass with the covariance records staged trajectory-major (record_stage.h), in chunks of as many records as
-// `stage` holds: [records in] -> smoother launch over the chunk (carried state in the workspace) -> [smoothed records out].
-// Fixed grids only (every trajectory has the same records).  stage_doubles must hold at least two records.
-int launch_smooth_d28_staged(int q, const SmoothParams& P0, double* ws, double* stage, size_t stage_doubles, hipStream_t s) {
-  const long n = P0.n_save, N = P0.N;
+// The same pass with the covariance records staged trajectory-major (record_stage.h), in blocks of as many records as
+// `stage` holds, from the last record down: [records in] -> smoother launch over the block (carried state in the workspace)
+// -> [records out].  `n_rec`: number of save slots in use (fixed grids: n_save; adaptive: the largest nsaved of the
+// ensemble -- every trajectory joins in at the block that holds its own last record).  stage_doubles must hold at
+// least two records.
+int launch_smooth_d28_staged(int q, const SmoothParams& P0, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s) {
+  const long n = n_rec, N = P0.N;
   const long D = 28L * (q + 1), TRI = D * (D + 1) / 2, ld = stage_record_ld(TRI);
   const size_t per_rec = (size_t)N * (size_t)ld;
   const long cap = (long)(stage_doubles / per_rec);
-  if (n < 3 || cap < 2 || P0.adaptive || pleiades_smooth_team()) return -4;  // the caller runs the pass on the records in place
-  // records 0 and n - 1 are not smoothed (src/smoothing.jl:11)
-  const size_t rec_bytes = (size_t)TRI * (size_t)N * sizeof(double);
-  if (hipMemcpyAsync(P0.scov, P0.cov, rec_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return -5;
-  if (hipMemcpyAsync(P0.scov + (size_t)(n - 1) * TRI * N, P0.cov + (size_t)(n - 1) * TRI * N, rec_bytes, hipMemcpyDeviceToDevice, s) !=
-      hipSuccess)
-    return -5;
-  long top = n - 2;  // highest record still to smooth
-  bool first = true;
+  if (n < 2 || n > P0.n_save || cap < 2 || pleiades_smooth_team()) return -4;  // the caller runs the pass on the records in place
+  // record 0 is never smoothed (src/smoothing.jl:11) and never staged: copied here (a trajectory that has no other record
+  // is not visited by any launch)
+  if (hipMemcpyAsync(P0.scov, P0.cov, (size_t)TRI * (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return -5;
+  if (hipMemcpyAsync(P0.smean, P0.mean, (size_t)D * (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return -5;
+  long top = n - 1;  // highest record not yet through the stage
   while (top >= 1) {
-    const long hi = first ? n - 1 : top;  // the first chunk carries the last record (start of the carried state)
-    const long lo = hi - cap + 1 > 1 ? hi - cap + 1 : 1;
+    const long hi = top, lo = hi - cap + 1 > 1 ? hi - cap + 1 : 1;
     SmoothParams P = P0;
     P.stage = stage;
     P.stage_s0 = lo;
+    P.stage_hi = hi;
     P.stage_ld = ld;
-    P.s_lo = lo;
-    P.s_hi = top;
-    P.resume = first ? 0 : 1;
     launch_stage_copy(true, P0.cov + (size_t)lo * TRI * N, stage, N, TRI, ld, hi - lo + 1, s);
     LaunchTeamSmooth f{P, ws, s};
     const int rc = dispatch_smooth_order<28>(q, f);
     if (rc) return rc;
-    launch_stage_copy(false, stage, P0.scov + (size_t)lo * TRI * N, N, TRI, ld, top - lo + 1, s);
+    launch_stage_copy(false, stage, P0.scov + (size_t)lo * TRI * N, N, TRI, ld, hi - lo + 1, s);
     top = lo - 1;
-    first = false;
   }
   return 0;
 }

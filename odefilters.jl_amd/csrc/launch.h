@@ -29,7 +29,7 @@ int launch_filter_pleiades(int q, int ek1, const TeamFilterParams& TP, hipStream
 int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive = 0, double* stage = nullptr,
                                  size_t stage_doubles = 0);  // register-tiled kernel (default)
 int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s);
-int launch_smooth_d28_staged(int q, const SmoothParams& P, double* ws, double* stage, size_t stage_doubles, hipStream_t s);
+int launch_smooth_d28_staged(int q, const SmoothParams& P, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s);
 int launch_dense_d28(int q, const DenseParams& P, double* ws, hipStream_t s);  // ws: dense_d28_grid(N n_q) x team_smooth_ws_doubles
 long dense_d28_grid(long items);
 int launch_sample_d28(int q, const SampleParams& P, double* ws, hipStream_t s);  // ws: dense_d28_grid(N n_samples) x team_smooth_ws_doubles

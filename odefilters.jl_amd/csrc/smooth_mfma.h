@@ -246,9 +246,19 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
   // Staged pass (fixed grids, api.hip): the covariance records of this launch lie trajectory-major in P.stage -- one record is
   // stage_ld contiguous doubles, read and written as whole lines -- instead of as 8-byte pieces N doubles apart.
   const bool staged = P.stage != nullptr;
-  const long s_hi = staged ? P.s_hi : n - 2, s_lo = staged ? P.s_lo : 1;
+  const long s_hi = staged ? (n - 2 < P.stage_hi ? n - 2 : P.stage_hi) : n - 2, s_lo = staged ? (P.stage_s0 > 1 ? P.stage_s0 : 1) : 1;
   auto rec = [&](long s) -> double* { return P.stage + ((size_t)(s - P.stage_s0) * N + (size_t)i) * (size_t)P.stage_ld; };
-  if (!staged || !P.resume) {
+  if (staged) {
+    // save slots this trajectory never used (adaptive solves: n differs between trajectories) leave the stage as zeros,
+    // as the in-place pass leaves them
+    for (long s = (n > P.stage_s0 ? n : P.stage_s0); s <= P.stage_hi; ++s) {
+      double* dst = rec(s);
+      for (int e = tid; e < (int)P.stage_ld; e += nth) dst[e] = 0.0;
+    }
+    if (n - 1 < P.stage_s0) return;  // (workgroup-uniform) its records all lie below this block of the stage
+  }
+  const bool resume = staged && n - 1 > P.stage_hi;  // started in an earlier launch, from a block further up
+  if (!resume) {
     // zero the workspace once (padding rows / columns stay zero from here on); L = U' must be zero above the diagonal
     for (size_t e = tid; e < W::size; e += nth) ws[e] = 0.0;
     __syncthreads();

@@ -446,6 +446,39 @@ def test_pleiades_adaptive(pkg, kind, q):
         assert sol.t[i, n - 1] == t1
 
 
+def test_pleiades_adaptive_smoother_record_stage(pkg, monkeypatch):
+    """Adaptive solves give every trajectory its own number of records: the staged smoother pass (csrc/record_stage.h) lets
+    each trajectory join in at the block of the stage that holds its last record.  Whole stage, blocks of a few records and
+    the in-place pass agree bit for bit, unused save slots stay zero; the tolerances are set so that record counts differ."""
+    vf = orc.vector_field("pleiades")
+    N, q, t1 = 70, 2, 0.06
+    D = 28 * (q + 1)
+    per_rec_mb = N * ((D * (D + 1) // 2 + 15) // 16 * 16) * 8 / 2**20
+    out = {}
+    for name, mb in (("whole", None), ("blocks", str(int(np.ceil(3.2 * per_rec_mb)))), ("in place", "0")):
+        if mb is None:
+            monkeypatch.delenv("ODEF_SMOOTH_STAGE_MB", raising=False)
+        else:
+            monkeypatch.setenv("ODEF_SMOOTH_STAGE_MB", mb)
+        ctx = pkg.Context("pleiades", q, 1, N, save_everystep=True)
+        ctx.set_problem_perturbed(vf.u0, [], 0.0, 3e-2, n_perturbed=14)
+        ctx.solve_adaptive(t1, 1e-7, 1e-5, 0.02, None, 63)
+        ctx.smooth()
+        assert (ctx.get(10) == 0).all()
+        out[name] = (ctx.get(11).copy(), ctx.get(12).copy(), ctx.get(9).copy())
+        ctx.close()
+    ns = out["whole"][2]
+    assert ns.min() >= 3 and ns.max() > ns.min() and ns.max() < out["whole"][1].shape[0]
+    sm, sc = out["whole"][0], out["whole"][1]
+    assert np.isfinite(sm).all() and np.isfinite(sc).all()
+    for i in (0, int(np.argmin(ns)), int(np.argmax(ns))):
+        assert (sc[ns[i]:, :, i] == 0).all() and np.abs(sc[ns[i] - 1, :, i]).max() > 0
+    for name in ("blocks", "in place"):
+        np.testing.assert_array_equal(out[name][2], ns)
+        np.testing.assert_array_equal(out[name][0], sm, err_msg=name)
+        np.testing.assert_array_equal(out[name][1], sc, err_msg=name)
+
+
 @pytest.mark.parametrize("kind,q", [("EK1", 3), ("EK0", 5)])
 def test_pleiades_adaptive_mfma_kernel_against_tiles_kernel(pkg, kind, q, monkeypatch):
     """The two adaptive D = 28 (q+1) filters -- matrix cores / Joseph form (MfmaFilter::run_adaptive, default) and register

@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
     for (size_t r = 0; r < (size_t)(ns - 1) * N; ++r)
       for (int e = 0; e < TRI; ++e) st[r * ld + e] = cov1[e];
     P.stage = (double*)dev(st.data(), st.size() * 8);
-    P.stage_s0 = 1; P.stage_ld = ld; P.s_lo = 1; P.s_hi = ns - 2; P.resume = 0;
+    P.stage_s0 = 1; P.stage_ld = ld; P.stage_hi = ns - 1;
   }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 2; ++rep) {
