@@ -121,6 +121,47 @@ def test_config4_pleiades_8192_final_state(pkg):
     ctx.close()
 
 
+def test_pleiades_1024_every_step_and_smoother_properties(pkg):
+    """The D = 168 every-step filter and smoother at a size where the record stage (csrc/record_stage.h) works on gigabytes
+    (1 024 trajectories x 32 steps x 113 KB per record, filter records and smoothed records through it): properties that
+    do not need the oracle -- every record finite with non-negative variances, the last smoothed record IS the last filter
+    record, duplicated inputs give bit-identical outputs wherever they sit in the ensemble, the every-step solve ends in
+    the final-state solve's record, and smoothing does not increase the variances of the solution block."""
+    N, ns, dt = 1024, 32, 2.0**-10
+    base = np.array([3, 3, -1, -3, 2, -2, 2, 3, -3, 2, 0, 0, -4, 4, 0, 0, 0, 0, 0, 1.75, -1.5, 0, 0, 0, -1.25, 1, 0, 0], float)
+    rng = np.random.default_rng(5)
+    u0 = base[:, None] + 1e-3 * np.concatenate([rng.standard_normal((14, N)), np.zeros((14, N))])
+    u0[:, 777] = u0[:, 3]  # duplicates far apart (different workgroups, different XCDs)
+    u0[:, 1023] = u0[:, 64]
+    ctx = pkg.Context("pleiades", 3, 1, N, smooth=True)
+    ctx.set_problem(u0.T.copy(), [], 0.0)
+    ctx.solve_fixed(np.arange(ns + 1) * dt)
+    ctx.smooth()
+    assert (ctx.get(10) == 0).all()
+    mean, cov, smean, scov = ctx.get(0), ctx.get(1), ctx.get(11), ctx.get(12)
+    D = 112
+    diag = np.array([k * (k + 1) // 2 + k for k in range(D)])
+    for a in (mean, cov, smean, scov):
+        assert np.isfinite(a).all()
+    assert (cov[:, diag] >= 0).all() and (scov[:, diag] >= 0).all()
+    np.testing.assert_array_equal(smean[-1], mean[-1])
+    np.testing.assert_array_equal(scov[-1], cov[-1])
+    np.testing.assert_array_equal(scov[0], cov[0])
+    for a in (mean, cov, smean, scov):
+        np.testing.assert_array_equal(a[:, :, 777], a[:, :, 3])
+        np.testing.assert_array_equal(a[:, :, 1023], a[:, :, 64])
+    # smoothing conditions on more data: the variances of u do not grow (up to rounding on the scale of the record)
+    vu_f, vu_s = cov[1:-1, diag[:28]], scov[1:-1, diag[:28]]
+    assert (vu_s <= vu_f * (1 + 1e-9) + 1e-30).all()
+    ctx.close()
+    ctx2 = pkg.Context("pleiades", 3, 1, N, save_everystep=False)
+    ctx2.set_problem(u0.T.copy(), [], 0.0)
+    ctx2.solve_fixed(np.arange(ns + 1) * dt)
+    np.testing.assert_array_equal(ctx2.get(0)[0], mean[-1])
+    np.testing.assert_array_equal(ctx2.get(1)[0], cov[-1])
+    ctx2.close()
+
+
 def test_config5_lorenz_16384_adaptive_and_smoother(pkg):
     """configs[4]: Lorenz-63 EK1(3), 16 384 trajectories, adaptive PI step-size control + RTS smoothing."""
     fx = np.load(os.path.join(GOLD, "full_lorenz_adaptive.npz"))
