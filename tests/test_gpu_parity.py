@@ -546,6 +546,25 @@ def test_pleiades_fixed_diffusion(pkg, model):
     assert P.cov_err(sol.x_smooth_cov()[0], ref.covs(smoothed=True)) < 1e-6
 
 
+@pytest.mark.parametrize("model", ["fixed", "fixedMAP"])
+def test_pleiades_fixed_diffusion_adaptive(pkg, model):
+    """The static diffusion models under the adaptive controller on the matrix-core kernel (MfmaFilter::run_adaptive): the
+    running estimate advances on accepted attempts only and is put back on a rejected one, the error estimate uses the local
+    diffusion of the attempt; against the oracle's loop, with rejected attempts in the run."""
+    vf = orc.vector_field("pleiades")
+    t1, dt0 = 0.04, 0.02
+    tol = dict(abstol=1e-8, reltol=1e-6)
+    prob = pkg.ODEProblem("pleiades", vf.u0, (0.0, t1), ())
+    sol = pkg.solve(prob, pkg.EK1(order=2, diffusionmodel=model), adaptive=True, dt=dt0, max_steps=256, **tol)
+    assert sol.retcode == ["Success"]
+    ref = orc.solve(vf, orc.Alg("EK1", 2, model, True), adaptive=True, dt=dt0, tspan=(0.0, t1), **tol)
+    n = int(sol.nsaved[0])
+    assert ref.nreject >= 1 and int(sol.destats.nreject[0]) == ref.nreject and n == len(ref.t)
+    np.testing.assert_allclose(sol.t[0, :n], ref.t, rtol=1e-6)
+    np.testing.assert_allclose(sol.u[0, :n], ref.u, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(sol.diffusions[0, : n - 1], ref.diffusions, rtol=1e-5)
+
+
 # ---- dense output / saveat (src/solution.jl:165-210) -----------------------------------------------
 
 
