@@ -338,6 +338,78 @@ __global__ __launch_bounds__(kTeamBig, 4) void rts_smooth_mfma_kernel(const Smoo
   if (i < 0) return;
   smooth_mfma_traj<d, q>(P, i, ws + (size_t)i * W::size, lds);
 }
+// The two block sweeps of ONE record for every trajectory, with the factor on chip (split pass, the default of the staged smoother; prototype and
+// measurements: tools/onchip_sweep_proto.hip): one workgroup of DPB wavefronts per trajectory, U (upper tiles, rows padded to
+// 17 doubles so that the transposed reads of the backward sweep are bank-conflict free) and the inverted diagonal blocks in LDS,
+// wavefront c holds tile column c of the right-hand sides in its accumulators for both sweeps -- no barrier, no re-read.
+template <int d, int q>
+__global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth_sweeps_kernel(const SmoothParams P, double* ws) {
+  using W = MfmaSmoothWs<d, q + 1>;
+  constexpr int DPB = W::DPB, DP = W::DP, LDT = 17, TSZ = mf::kB * LDT;
+  extern __shared__ double lds[];
+  const long i = team_traj(P.N);
+  if (i < 0) return;
+  double* my = ws + (size_t)i * W::size;
+  if ((long)my[W::FLG] != P.split_sa) return;  // (workgroup-uniform) no factor was prepared for this record
+  const int tid = (int)threadIdx.x, wave = tid >> 6, l = tid & 63;
+  const double* BM = my + W::BM;
+  double* YT = my + W::YT;
+  auto tix = [](int j, int jp) { return j * DPB - j * (j - 1) / 2 + (jp - j); };
+  // all threads load: element e of tile t = (j, jp >= j) in row order; block row j from t by counting down the row lengths
+  for (int e = tid; e < DPB * (DPB + 1) / 2 * 256; e += (int)blockDim.x) {
+    const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;
+    int j = 0, rest = t;
+    while (rest >= DPB - j) {
+      rest -= DPB - j;
+      ++j;
+    }
+    const int jp = j + rest;
+    lds[t * TSZ + r * LDT + c] = (j == jp) ? my[W::WBL + j * 256 + (e & 255)] : BM[(size_t)(j * 16 + r) * DP + jp * 16 + c];
+  }
+  __syncthreads();
+  const int c0 = wave * mf::kB;
+  mf::d4 acc[DPB];
+#pragma unroll
+  for (int j = 0; j < DPB; ++j) acc[j] = mf::load_tile(YT, DP, j * mf::kB, c0);
+  static_for<0, DPB>([&](auto jc) {  // forward: Z_j = W_j acc_j, acc_j' -= U[j, j']' Z_j for j' > j
+    constexpr int j = decltype(jc)::value;
+    const double* w = lds + tix(j, j) * TSZ;
+    mf::d4 z0 = mf::zero4();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) z0 = mf::mfma(w[(l & 15) * LDT + 4 * kk + (l >> 4)], acc[j][kk], z0);
+    acc[j] = z0;
+    const mf::d4 z = -z0;
+    static_for<j + 1, DPB>([&](auto jpc) {
+      constexpr int jp = decltype(jpc)::value;
+      const double* t = lds + tix(j, jp) * TSZ;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc[jp] = mf::mfma(t[(4 * ks + (l >> 4)) * LDT + (l & 15)], z[ks], acc[jp]);
+      asm volatile("" ::: "memory");  // keeps the compiler from hoisting (and spilling) the fragment reads of all later tiles
+    });
+  });
+  static_for<0, DPB>([&](auto jc) {  // backward: Gt_j = W_j' acc_j, acc_j' -= U[j', j] Gt_j for j' < j
+    constexpr int j = DPB - 1 - decltype(jc)::value;
+    const double* w = lds + tix(j, j) * TSZ;
+    mf::d4 g0 = mf::zero4();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) g0 = mf::mfma(w[(4 * kk + (l >> 4)) * LDT + (l & 15)], acc[j][kk], g0);
+    acc[j] = g0;
+    const mf::d4 g = -g0;
+    static_for<0, j>([&](auto jpc) {
+      constexpr int jp = decltype(jpc)::value;
+      const double* t = lds + tix(jp, j) * TSZ;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc[jp] = mf::mfma(t[(l & 15) * LDT + 4 * ks + (l >> 4)], g[ks], acc[jp]);
+      asm volatile("" ::: "memory");
+    });
+  });
+#pragma unroll
+  for (int j = 0; j < DPB; ++j) mf::store_tile(YT, DP, j * mf::kB, c0, acc[j]);
+}
+inline bool pleiades_smooth_split() {  // the staged pass as a sequence of kernels per record (default); ODEF_SMOOTH_SPLIT=0: one persistent launch per block
+  const char* e = getenv("ODEF_SMOOTH_SPLIT");
+  return !(e && e[0] == '0');
+}
 inline bool pleiades_smooth_team() {  // ODEF_PLEIADES_SMOOTH=team: the first (vector-FMA) D = 168 smoother, for A/B comparison
   const char* e = getenv("ODEF_PLEIADES_SMOOTH");
   return e && e[0] == 't';
@@ -397,6 +469,26 @@ struct LaunchTeamDense {
 };
 #endif
 
+struct LaunchTeamSmoothSweeps {
+  const SmoothParams& P;
+  double* ws;
+  hipStream_t s;
+  int rc = 0;
+  template <int d, int q>
+  void operator()() {
+    using W = MfmaSmoothWs<d, q + 1>;
+    constexpr size_t lds_bytes = (size_t)(W::DPB * (W::DPB + 1) / 2) * mf::kB * 17 * sizeof(double);
+    static bool attr_set = false;  // (per instantiation)
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)rts_smooth_sweeps_kernel<d, q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+        rc = -6;
+        return;
+      }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((rts_smooth_sweeps_kernel<d, q>), dim3(team_grid(P.N)), dim3(64 * W::DPB), lds_bytes, s, P, ws);
+  }
+};
 struct LaunchTeamSmooth {
   const SmoothParams& P;
   double* ws;

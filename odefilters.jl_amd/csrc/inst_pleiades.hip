@@ -75,9 +75,38 @@ int launch_smooth_d28_staged(int q, const SmoothParams& P0, long n_rec, double* 
     P.stage_hi = hi;
     P.stage_ld = ld;
     launch_stage_copy(true, P0.cov + (size_t)lo * TRI * N, stage, N, TRI, ld, hi - lo + 1, s);
-    LaunchTeamSmooth f{P, ws, s};
-    const int rc = dispatch_smooth_order<28>(q, f);
-    if (rc) return rc;
+    if (!pleiades_smooth_split()) {
+      LaunchTeamSmooth f{P, ws, s};
+      const int rc = dispatch_smooth_order<28>(q, f);
+      if (rc) return rc;
+    } else {
+      // one kernel per phase and record: [set up the block] then, record by record from the top,
+      // [finish record r + 1 | begin record r] -> [sweeps of record r with the factor in LDS]; trajectories that do not have
+      // the record (adaptive solves) or repeat a save time skip their part inside the kernels
+      P.split_mode = 1;
+      P.split_sc = P.split_sa = -1;
+      {
+        LaunchTeamSmooth f{P, ws, s};
+        const int rc = dispatch_smooth_order<28>(q, f);
+        if (rc) return rc;
+      }
+      const long r_hi = hi < n - 2 ? hi : n - 2, r_lo = lo;
+      P.split_mode = 2;
+      for (long r = r_hi; r >= r_lo - 1; --r) {
+        P.split_sc = r + 1 <= r_hi ? r + 1 : -1;
+        P.split_sa = r >= r_lo ? r : -1;
+        {
+          LaunchTeamSmooth f{P, ws, s};
+          const int rc = dispatch_smooth_order<28>(q, f);
+          if (rc) return rc;
+        }
+        if (P.split_sa >= 0) {
+          LaunchTeamSmoothSweeps g{P, ws, s};
+          const int rc = dispatch_smooth_order<28>(q, g);
+          if (rc || g.rc) return rc ? rc : g.rc;
+        }
+      }
+    }
     launch_stage_copy(false, stage, P0.scov + (size_t)lo * TRI * N, N, TRI, ld, hi - lo + 1, s);
     top = lo - 1;
   }

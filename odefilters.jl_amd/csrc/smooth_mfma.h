@@ -45,7 +45,10 @@ struct MfmaSmoothWs {
   static constexpr int D = d * NB, DPB = (D + 15) / 16, DP = DPB * 16, MAT = DP * DP;
   static constexpr int X = 0, YT = MAT, BM = 2 * MAT, LM = 3 * MAT, MM = 4 * MAT, Z2 = 5 * MAT, SG = 6 * MAT;
   static constexpr int MSV = 7 * MAT;  // the carried smoothed mean between the launches of a staged pass
-  static constexpr size_t size = 7 * (size_t)MAT + DP;
+  // split pass (one kernel per phase): what the phases of a record hand over -- P m, delta, P^-1 (vectors), the inverted
+  // diagonal blocks of the factor, and the record index the hand-over belongs to (-1: that record needs no algebra)
+  static constexpr int MFV = MSV + DP, DLV = MFV + DP, PIJV = DLV + DP, WBL = PIJV + DP, FLG = WBL + DPB * 256;
+  static constexpr size_t size = (size_t)FLG + 8;
   // LDS (doubles): factorisation scratch, then the vectors
   static constexpr int kChol = mf::CholLds<DPB>::size;
   static constexpr int MF = kChol, MS = MF + DP, MP = MS + DP, DL = MP + DP, PJ = DL + DP, PIJ = PJ + DP;
@@ -162,7 +165,9 @@ __device__ __attribute__((always_inline)) inline void mfma_predict_phase(const P
   __syncthreads();
   ODEF_STAMP(2);  // B, M
 }
-template <int d, int q>
+// PART: 7 = all of it; 1 = the Cholesky only; 4 = what follows the sweeps (mean, products) -- the split pass runs the sweeps
+// (2) in a kernel of their own
+template <int d, int q, int PART = 7>
 __device__ __attribute__((always_inline)) inline bool mfma_gain_phase(double* __restrict__ ws, double* __restrict__ lds) {
   using W = MfmaSmoothWs<d, q + 1>;
   constexpr int NB = q + 1, D = W::D, DP = W::DP, DPB = W::DPB;
@@ -183,8 +188,12 @@ __device__ __attribute__((always_inline)) inline bool mfma_gain_phase(double* __
   (void)X; (void)YT; (void)BM; (void)LM; (void)MM; (void)Z2; (void)SG; (void)mf_; (void)ms_; (void)mp_; (void)dl_; (void)pj_; (void)pij_; (void)DPB; (void)NB;
   bool nan_seen = false;
   // B = U'U, Gt = B^-1 Yt (the gain G = X A' (Sigma^-)^-1, src/smoothing.jl:42-43, transposed)
-  mf::wg_cholesky_upper<DPB>(BM, LM, DP, lds);
-  ODEF_STAMP(3);  // Cholesky
+  if (PART & 1) {
+    mf::wg_cholesky_upper<DPB>(BM, LM, DP, lds);
+    ODEF_STAMP(3);  // Cholesky
+  }
+  if (PART == 1) return false;
+  if (PART & 2) {
 #ifndef ODEF_SMOOTH_RR
   mf::wg_solve_upper<DPB>(BM, LM, YT, DP, lds);  // left-looking: 22 block steps, a barrier after each
 #else  // A/B build: right-hand sides resident in the accumulators, no barrier inside -- measured 1.5x SLOWER (see mfma_dense.h)
@@ -192,6 +201,7 @@ __device__ __attribute__((always_inline)) inline bool mfma_gain_phase(double* __
   __syncthreads();
 #endif
   ODEF_STAMP(4);  // sweeps
+  }
   // m^s = m + G delta (src/smoothing.jl:44), un-preconditioned (:26)
   for (int k = tid; k < D; k += nth) {
     double t = mf_[k];
@@ -248,16 +258,16 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
   const bool staged = P.stage != nullptr;
   const long s_hi = staged ? (n - 2 < P.stage_hi ? n - 2 : P.stage_hi) : n - 2, s_lo = staged ? (P.stage_s0 > 1 ? P.stage_s0 : 1) : 1;
   auto rec = [&](long s) -> double* { return P.stage + ((size_t)(s - P.stage_s0) * N + (size_t)i) * (size_t)P.stage_ld; };
-  if (staged) {
+  if (staged && P.split_mode != 2) {
     // save slots this trajectory never used (adaptive solves: n differs between trajectories) leave the stage as zeros,
     // as the in-place pass leaves them
     for (long s = (n > P.stage_s0 ? n : P.stage_s0); s <= P.stage_hi; ++s) {
       double* dst = rec(s);
       for (int e = tid; e < (int)P.stage_ld; e += nth) dst[e] = 0.0;
     }
-    if (n - 1 < P.stage_s0) return;  // (workgroup-uniform) its records all lie below this block of the stage
   }
-  const bool resume = staged && n - 1 > P.stage_hi;  // started in an earlier launch, from a block further up
+  if (staged && n - 1 < P.stage_s0) return;  // (workgroup-uniform) its records all lie below this block of the stage
+  const bool resume = staged && (n - 1 > P.stage_hi || P.split_mode == 2);  // started in an earlier launch
   if (!resume) {
     // zero the workspace once (padding rows / columns stay zero from here on); L = U' must be zero above the diagonal
     for (size_t e = tid; e < W::size; e += nth) ws[e] = 0.0;
@@ -295,7 +305,12 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
   }
   __syncthreads();
   bool nan_seen = false;
-  for (long s = s_hi; s >= s_lo; --s) {
+  // One record in two parts with the sweeps between them: the persistent loop runs A, sweeps, C back to back; the split
+  // pass (P.split_mode == 2) runs C of the previous record and A of the next one here and the sweeps in a kernel of their own.
+  // part A: unpack, predict, Cholesky.  Returns false for a repeated save time (src/smoothing.jl:13-16: the smoothed state
+  // carries over, nothing to factorise).
+  auto part_a = [&](long s, auto split) -> bool {
+    constexpr bool SPLIT = decltype(split)::value;
     double h;
     if (P.adaptive) h = P.tsave[(size_t)(s + 1) * N + i] - P.tsave[(size_t)s * N + i];
     else h = uniform_load(P.hs + s);
@@ -309,7 +324,7 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
         for (int e = tid; e < TRI; e += nth) P.scov[((size_t)s * TRI + e) * N + i] = P.scov[((size_t)(s + 1) * TRI + e) * N + i];
       }
       __syncthreads();
-      continue;
+      return false;
     }
     // preconditioner of this step (src/preconditioning.jl:1-17), per state component
     if (tid < DP) {
@@ -366,7 +381,30 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
     __syncthreads();
     ODEF_STAMP(0);  // unpack
     mfma_predict_phase<d, q>(pc, sigma2, ws, lds);
-    nan_seen = mfma_gain_phase<d, q>(ws, lds) || nan_seen;
+    if constexpr (SPLIT) {
+      (void)mfma_gain_phase<d, q, 1>(ws, lds);
+      // hand-over to the sweeps kernel and to part C: the inverted diagonal blocks, P m, delta, P^-1
+      for (int e = tid; e < DPB * 256; e += nth) ws[W::WBL + e] = lds[mf::CholLds<DPB>::w + e];
+      for (int k = tid; k < DP; k += nth) {
+        ws[W::MFV + k] = mf_[k];
+        ws[W::DLV + k] = dl_[k];
+        ws[W::PIJV + k] = pij_[k];
+      }
+    }
+    return true;
+  };
+  // part C: smoothed mean, the two products, pack and store
+  auto part_c = [&](long s, auto split) {
+    constexpr bool SPLIT = decltype(split)::value;
+    if constexpr (SPLIT) {
+      for (int k = tid; k < DP; k += nth) {
+        mf_[k] = ws[W::MFV + k];
+        dl_[k] = ws[W::DLV + k];
+        pij_[k] = ws[W::PIJV + k];
+      }
+      __syncthreads();
+      nan_seen = mfma_gain_phase<d, q, 4>(ws, lds) || nan_seen;
+    }
     for (int k = tid; k < D; k += nth) P.smean[((size_t)s * D + k) * N + i] = ms_[k];
     // Sigma^s = P^-1 (X + G M G') P^-1: the record (packed lower triangle) and the carried full matrix
     if (staged) {  // by tiles, as the unpacking above; the lower triangle of the sum is what both halves of SG get
@@ -411,6 +449,24 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
     }
     __syncthreads();
     ODEF_STAMP(8);  // pack + store
+    };
+  if (P.split_mode == 2) {
+    // the hand-over flag: the record index part A prepared (-1: none, or a repeated save time)
+    const long prepared = (long)ws[W::FLG];
+    __syncthreads();
+    if (P.split_sc >= s_lo && P.split_sc <= s_hi && prepared == P.split_sc) part_c(P.split_sc, std::true_type{});
+    bool active = false;
+    if (P.split_sa >= s_lo && P.split_sa <= s_hi) active = part_a(P.split_sa, std::true_type{});
+    __syncthreads();
+    if (tid == 0) ws[W::FLG] = active ? (double)P.split_sa : -1.0;
+  } else if (P.split_mode == 0) {
+    for (long s = s_hi; s >= s_lo; --s) {
+      if (!part_a(s, std::false_type{})) continue;
+      nan_seen = mfma_gain_phase<d, q>(ws, lds) || nan_seen;
+      part_c(s, std::false_type{});
+    }
+  } else {
+    if (tid == 0) ws[W::FLG] = -1.0;
   }
   if (staged) {
     for (int k = tid; k < D; k += nth) ws[W::MSV + k] = ms_[k];

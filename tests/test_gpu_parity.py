@@ -403,11 +403,14 @@ def test_pleiades_smoother_record_stage(pkg, q, monkeypatch):
     D = 28 * (q + 1)
     per_rec_mb = N * ((D * (D + 1) // 2 + 15) // 16 * 16) * 8 / 2**20
     out = {}
-    for name, mb in (("whole", None), ("chunks", str(int(np.ceil(3.2 * per_rec_mb)))), ("in place", "0")):
+    monkeypatch.setenv("ODEF_SMOOTH_SPLIT", "0")  # one persistent launch per block, the same arithmetic as the in-place pass
+    for name, mb in (("whole", None), ("chunks", str(int(np.ceil(3.2 * per_rec_mb)))), ("in place", "0"), ("split", None),
+                     ("split chunks", str(int(np.ceil(3.2 * per_rec_mb))))):
         if mb is None:
             monkeypatch.delenv("ODEF_SMOOTH_STAGE_MB", raising=False)
         else:
             monkeypatch.setenv("ODEF_SMOOTH_STAGE_MB", mb)
+        monkeypatch.setenv("ODEF_SMOOTH_SPLIT", "1" if name.startswith("split") else "0")
         ctx = pkg.Context("pleiades", q, 1, N, save_everystep=True)
         ctx.set_problem_perturbed(vf.u0, [], 0.0, 1e-3, n_perturbed=14)
         ctx.solve_fixed(grid)
@@ -422,6 +425,15 @@ def test_pleiades_smoother_record_stage(pkg, q, monkeypatch):
         # the filter in front of it writes its records through the same stage when all of them fit ("whole" only)
         np.testing.assert_array_equal(out[name][2], out["whole"][2], err_msg=name)
         np.testing.assert_array_equal(out[name][3], out["whole"][3], err_msg=name)
+    # the split pass (default: a kernel per phase and record, the sweeps with the factor in LDS) orders the sweeps' sums
+    # differently: same results to rounding, whole stage and blocks bit-identical to each other
+    np.testing.assert_array_equal(out["split chunks"][0], out["split"][0])
+    np.testing.assert_array_equal(out["split chunks"][1], out["split"][1])
+    D_ = 28 * (q + 1)
+    sd = np.sqrt(np.maximum(out["whole"][1][:, [k * (k + 1) // 2 + k for k in range(D_)]], 0.0))
+    assert (np.abs(out["split"][0] - out["whole"][0]) <= (1e-12 if q < 5 else 1e-4) * (np.abs(out["whole"][0]) + sd) + 1e-300).all()
+    scale = np.abs(out["whole"][1]).max(axis=1, keepdims=True)
+    assert (np.abs(out["split"][1] - out["whole"][1]) <= (1e-12 if q < 5 else 1e-8) * scale + 1e-300).all()
 
 
 @pytest.mark.parametrize("kind,q", [("EK1", 2), ("EK0", 3), ("EK1", 5)])
@@ -455,11 +467,13 @@ def test_pleiades_adaptive_smoother_record_stage(pkg, monkeypatch):
     D = 28 * (q + 1)
     per_rec_mb = N * ((D * (D + 1) // 2 + 15) // 16 * 16) * 8 / 2**20
     out = {}
-    for name, mb in (("whole", None), ("blocks", str(int(np.ceil(3.2 * per_rec_mb)))), ("in place", "0")):
+    for name, mb in (("whole", None), ("blocks", str(int(np.ceil(3.2 * per_rec_mb)))), ("in place", "0"), ("split", None),
+                     ("split blocks", str(int(np.ceil(3.2 * per_rec_mb))))):
         if mb is None:
             monkeypatch.delenv("ODEF_SMOOTH_STAGE_MB", raising=False)
         else:
             monkeypatch.setenv("ODEF_SMOOTH_STAGE_MB", mb)
+        monkeypatch.setenv("ODEF_SMOOTH_SPLIT", "1" if name.startswith("split") else "0")
         ctx = pkg.Context("pleiades", q, 1, N, save_everystep=True)
         ctx.set_problem_perturbed(vf.u0, [], 0.0, 3e-2, n_perturbed=14)
         ctx.solve_adaptive(t1, 1e-7, 1e-5, 0.02, None, 63)
@@ -477,6 +491,15 @@ def test_pleiades_adaptive_smoother_record_stage(pkg, monkeypatch):
         np.testing.assert_array_equal(out[name][2], ns)
         np.testing.assert_array_equal(out[name][0], sm, err_msg=name)
         np.testing.assert_array_equal(out[name][1], sc, err_msg=name)
+    # the split pass (a kernel per phase and record; trajectories without the record skip inside the kernels)
+    np.testing.assert_array_equal(out["split"][2], ns)
+    np.testing.assert_array_equal(out["split blocks"][0], out["split"][0])
+    np.testing.assert_array_equal(out["split blocks"][1], out["split"][1])
+    for i in (0, int(np.argmin(ns)), int(np.argmax(ns))):
+        assert (out["split"][1][ns[i]:, :, i] == 0).all()
+    sd = np.sqrt(np.maximum(sc[:, [k * (k + 1) // 2 + k for k in range(D)]], 0.0))
+    assert (np.abs(out["split"][0] - sm) <= 1e-12 * (np.abs(sm) + sd) + 1e-300).all()
+    assert (np.abs(out["split"][1] - sc) <= 1e-12 * np.abs(sc).max(axis=1, keepdims=True) + 1e-300).all()
 
 
 @pytest.mark.parametrize("kind,q", [("EK1", 3), ("EK0", 5)])
