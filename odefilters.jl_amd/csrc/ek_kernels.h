@@ -338,10 +338,11 @@ __global__ __launch_bounds__(kTeamBig, 4) void rts_smooth_mfma_kernel(const Smoo
   if (i < 0) return;
   smooth_mfma_traj<d, q>(P, i, ws + (size_t)i * W::size, lds);
 }
-// The two block sweeps of ONE record for every trajectory, with the factor on chip (split pass, the default of the staged smoother; prototype and
-// measurements: tools/onchip_sweep_proto.hip): one workgroup of DPB wavefronts per trajectory, U (upper tiles, rows padded to
-// 17 doubles so that the transposed reads of the backward sweep are bank-conflict free) and the inverted diagonal blocks in LDS,
-// wavefront c holds tile column c of the right-hand sides in its accumulators for both sweeps -- no barrier, no re-read.
+// The Cholesky factorisation and the two block sweeps of ONE record for every trajectory, on chip (split pass, the default of
+// the staged smoother; prototype and measurements of the sweeps: tools/onchip_sweep_proto.hip): one workgroup of DPB
+// wavefronts per trajectory, the upper tiles of B in LDS (rows padded to 17 doubles so that the transposed reads of the
+// backward sweep are bank-conflict free), factorised there; then wavefront c holds tile column c of the right-hand sides
+// in its accumulators for both sweeps -- no barrier, no re-read, the factor never leaves the chip.
 template <int d, int q>
 __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth_sweeps_kernel(const SmoothParams P, double* ws) {
   using W = MfmaSmoothWs<d, q + 1>;
@@ -364,9 +365,59 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
       ++j;
     }
     const int jp = j + rest;
-    lds[t * TSZ + r * LDT + c] = (j == jp) ? my[W::WBL + j * 256 + (e & 255)] : BM[(size_t)(j * 16 + r) * DP + jp * 16 + c];
+    lds[t * TSZ + r * LDT + c] = BM[(size_t)(j * 16 + r) * DP + jp * 16 + c];
   }
   __syncthreads();
+  // B = U'U in LDS, right-looking by block rows: the diagonal tile is factorised by one wavefront and replaced by
+  // W_j = L_jj^-1 (what the sweeps multiply with), the tiles of block row j become U[j, .] = W_j (.), the tiles below take
+  // their rank-16 update.  1 100 MFMAs in all; what it costs is the 11 diagonal factorisations in sequence.
+  {
+    double* scratch = lds + DPB * (DPB + 1) / 2 * TSZ;  // 16 x 16 block + 16 reciprocals for diag_block_factor
+    const int nw = (int)blockDim.x >> 6;
+    for (int j = 0; j < DPB; ++j) {
+      double* tjj = lds + tix(j, j) * TSZ;
+      if (wave == 0) {
+        for (int e = l; e < 256; e += 64) scratch[e] = tjj[(e >> 4) * LDT + (e & 15)];
+        tv::lds_sync();
+        mf::diag_block_factor(scratch, nullptr, tjj, LDT);
+      }
+      __syncthreads();
+      for (int jp = j + 1 + wave; jp < DPB; jp += nw) {
+        double* t = lds + tix(j, jp) * TSZ;
+        mf::d4 r, u = mf::zero4();
+#pragma unroll
+        for (int v = 0; v < 4; ++v) r[v] = t[(4 * v + (l >> 4)) * LDT + (l & 15)];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) u = mf::mfma(tjj[(l & 15) * LDT + 4 * kk + (l >> 4)], r[kk], u);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) t[(4 * v + (l >> 4)) * LDT + (l & 15)] = u[v];
+      }
+      __syncthreads();
+      const int m = DPB - 1 - j;
+      for (int t = wave; t < m * (m + 1) / 2; t += nw) {
+        int a = j + 1, rest = t;
+        while (rest >= DPB - a) {
+          rest -= DPB - a;
+          ++a;
+        }
+        const int b = a + rest;
+        const double* ua = lds + tix(j, a) * TSZ;
+        const double* ub = lds + tix(j, b) * TSZ;
+        double* tab = lds + tix(a, b) * TSZ;
+        mf::d4 acc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = tab[(4 * v + (l >> 4)) * LDT + (l & 15)];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int o = (4 * ks + (l >> 4)) * LDT + (l & 15);
+          acc = mf::mfma(-ua[o], ub[o], acc);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) tab[(4 * v + (l >> 4)) * LDT + (l & 15)] = acc[v];
+      }
+      __syncthreads();
+    }
+  }
   const int c0 = wave * mf::kB;
   mf::d4 acc[DPB];
 #pragma unroll
@@ -477,7 +528,7 @@ struct LaunchTeamSmoothSweeps {
   template <int d, int q>
   void operator()() {
     using W = MfmaSmoothWs<d, q + 1>;
-    constexpr size_t lds_bytes = (size_t)(W::DPB * (W::DPB + 1) / 2) * mf::kB * 17 * sizeof(double);
+    constexpr size_t lds_bytes = ((size_t)(W::DPB * (W::DPB + 1) / 2) * mf::kB * 17 + 272) * sizeof(double);
     static bool attr_set = false;  // (per instantiation)
     if (!attr_set) {
       if (hipFuncSetAttribute((const void*)rts_smooth_sweeps_kernel<d, q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {

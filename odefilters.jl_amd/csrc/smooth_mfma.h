@@ -45,9 +45,9 @@ struct MfmaSmoothWs {
   static constexpr int D = d * NB, DPB = (D + 15) / 16, DP = DPB * 16, MAT = DP * DP;
   static constexpr int X = 0, YT = MAT, BM = 2 * MAT, LM = 3 * MAT, MM = 4 * MAT, Z2 = 5 * MAT, SG = 6 * MAT;
   static constexpr int MSV = 7 * MAT;  // the carried smoothed mean between the launches of a staged pass
-  // split pass (one kernel per phase): what the phases of a record hand over -- P m, delta, P^-1 (vectors), the inverted
-  // diagonal blocks of the factor, and the record index the hand-over belongs to (-1: that record needs no algebra)
-  static constexpr int MFV = MSV + DP, DLV = MFV + DP, PIJV = DLV + DP, WBL = PIJV + DP, FLG = WBL + DPB * 256;
+  // split pass (one kernel per phase): what the phases of a record hand over -- P m, delta, P^-1 (vectors) and the record
+  // index the hand-over belongs to (-1: that record needs no algebra)
+  static constexpr int MFV = MSV + DP, DLV = MFV + DP, PIJV = DLV + DP, FLG = PIJV + DP;
   static constexpr size_t size = (size_t)FLG + 8;
   // LDS (doubles): factorisation scratch, then the vectors
   static constexpr int kChol = mf::CholLds<DPB>::size;
@@ -307,7 +307,7 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
   bool nan_seen = false;
   // One record in two parts with the sweeps between them: the persistent loop runs A, sweeps, C back to back; the split
   // pass (P.split_mode == 2) runs C of the previous record and A of the next one here and the sweeps in a kernel of their own.
-  // part A: unpack, predict, Cholesky.  Returns false for a repeated save time (src/smoothing.jl:13-16: the smoothed state
+  // part A: unpack, predict (and, in the persistent loop, what follows).  Returns false for a repeated save time (src/smoothing.jl:13-16: the smoothed state
   // carries over, nothing to factorise).
   auto part_a = [&](long s, auto split) -> bool {
     constexpr bool SPLIT = decltype(split)::value;
@@ -382,9 +382,7 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
     ODEF_STAMP(0);  // unpack
     mfma_predict_phase<d, q>(pc, sigma2, ws, lds);
     if constexpr (SPLIT) {
-      (void)mfma_gain_phase<d, q, 1>(ws, lds);
-      // hand-over to the sweeps kernel and to part C: the inverted diagonal blocks, P m, delta, P^-1
-      for (int e = tid; e < DPB * 256; e += nth) ws[W::WBL + e] = lds[mf::CholLds<DPB>::w + e];
+      // hand-over to part C (the factorisation and the sweeps run in rts_smooth_sweeps_kernel): P m, delta, P^-1
       for (int k = tid; k < DP; k += nth) {
         ws[W::MFV + k] = mf_[k];
         ws[W::DLV + k] = dl_[k];

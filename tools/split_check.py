@@ -11,7 +11,7 @@ q = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 70
 adaptive = len(sys.argv) > 3 and sys.argv[3] == "adaptive"
 out = {}
-for name, env in (("persistent", "0"), ("split", "1")):
+for name, env in (("persistent", "0"), ("split", "1")):  # (split is the default)
     os.environ["ODEF_SMOOTH_SPLIT"] = env
     ctx = pkg.Context("pleiades", q, 1, N, save_everystep=True)
     ctx.set_problem_perturbed(vf.u0, [], 0.0, 3e-2 if adaptive else 1e-3, n_perturbed=14)
