@@ -458,6 +458,34 @@ def test_pleiades_adaptive(pkg, kind, q):
         assert sol.t[i, n - 1] == t1
 
 
+@pytest.mark.parametrize("q", [1, 3, 4])
+def test_pleiades_smoother_split_pass_orders(pkg, q, monkeypatch):
+    """The split pass of the D = 28 (q+1) smoother (a kernel per phase and record; factorisation and sweeps on chip in
+    rts_smooth_sweeps_kernel, one wavefront per tile column: 4, 7 and 9 wavefronts here) against the persistent kernel:
+    the same algebra in a different summation order.  Orders 2 and 5 are covered by test_pleiades_smoother_record_stage."""
+    vf = orc.vector_field("pleiades")
+    N = 20
+    grid = np.arange(10) * 2.0**-10
+    out = {}
+    for name, env in (("persistent", "0"), ("split", "1")):
+        monkeypatch.setenv("ODEF_SMOOTH_SPLIT", env)
+        ctx = pkg.Context("pleiades", q, 1, N, save_everystep=True)
+        ctx.set_problem_perturbed(vf.u0, [], 0.0, 1e-3, n_perturbed=14)
+        ctx.solve_fixed(grid)
+        ctx.smooth()
+        assert (ctx.get(10) == 0).all()
+        out[name] = (ctx.get(11).copy(), ctx.get(12).copy())
+        ctx.close()
+    (m0, c0), (m1, c1) = out["persistent"], out["split"]
+    assert np.isfinite(m1).all() and np.isfinite(c1).all()
+    D = 28 * (q + 1)
+    sd = np.sqrt(np.maximum(c0[:, [k * (k + 1) // 2 + k for k in range(D)]], 0.0))
+    tol = {1: 1e-13, 3: 1e-9, 4: 1e-7}[q]  # the higher orders' last derivative blocks are ill-conditioned (see DESIGN 4)
+    assert (np.abs(m1 - m0) <= tol * (np.abs(m0) + sd) + 1e-300).all()
+    assert (np.abs(c1 - c0) <= tol * np.abs(c0).max(axis=1, keepdims=True) + 1e-300).all()
+    np.testing.assert_allclose(m1[:, :28], m0[:, :28], rtol=1e-12, atol=1e-15)  # the solution block itself
+
+
 def test_pleiades_adaptive_smoother_record_stage(pkg, monkeypatch):
     """Adaptive solves give every trajectory its own number of records: the staged smoother pass (csrc/record_stage.h) lets
     each trajectory join in at the block of the stage that holds its last record.  Whole stage, blocks of a few records and
