@@ -330,13 +330,13 @@ struct LaunchTeamFilter {
 // The same pass on the matrix cores (smooth_mfma.h): 4 wavefronts per trajectory, matrices in a global workspace.
 // Four workgroups per CU (128 registers): the phases are bound by the latency and traffic of the global workspace, and more
 // resident workgroups hide more of it -- 319 / 307 / 273 ms with 2 / 3 / 4 (2 048 trajectories x 64 steps).
-template <int d, int q>
+template <int d, int q, bool SPLITK = false>
 __global__ __launch_bounds__(kTeamBig, 4) void rts_smooth_mfma_kernel(const SmoothParams P, double* ws) {
   using W = MfmaSmoothWs<d, q + 1>;
   __shared__ double lds[W::lds_size];
   const long i = team_traj(P.N);
   if (i < 0) return;
-  smooth_mfma_traj<d, q>(P, i, ws + (size_t)i * W::size, lds);
+  smooth_mfma_traj<d, q, SPLITK>(P, i, ws + (size_t)i * W::size, lds);
 }
 // The Cholesky factorisation and the two block sweeps of ONE record for every trajectory, on chip (split pass, the default of
 // the staged smoother; prototype and measurements of the sweeps: tools/onchip_sweep_proto.hip): one workgroup of DPB
@@ -548,8 +548,10 @@ struct LaunchTeamSmooth {
   void operator()() {
     if (pleiades_smooth_team())
       hipLaunchKernelGGL((rts_smooth_team_kernel<d, q>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
+    else if (P.split_mode != 0)
+      hipLaunchKernelGGL((rts_smooth_mfma_kernel<d, q, true>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
     else
-      hipLaunchKernelGGL((rts_smooth_mfma_kernel<d, q>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
+      hipLaunchKernelGGL((rts_smooth_mfma_kernel<d, q, false>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
   }
 };
 

@@ -230,7 +230,9 @@ __device__ __attribute__((always_inline)) inline bool mfma_gain_phase(double* __
   return nan_seen;
 }
 
-template <int d, int q>
+// SPLITK: the instantiation for the split pass (P.split_mode 1 / 2 only) -- a kernel of its own, so that neither carries the
+// other's code and registers
+template <int d, int q, bool SPLITK = false>
 __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const SmoothParams& P, long i, double* __restrict__ ws, double* __restrict__ lds) {
   constexpr int NB = q + 1;
   using W = MfmaSmoothWs<d, NB>;
@@ -448,7 +450,8 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
     __syncthreads();
     ODEF_STAMP(8);  // pack + store
     };
-  if (P.split_mode == 2) {
+  if constexpr (SPLITK) {
+   if (P.split_mode == 2) {
     // the hand-over flag: the record index part A prepared (-1: none, or a repeated save time)
     const long prepared = (long)ws[W::FLG];
     __syncthreads();
@@ -457,14 +460,15 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
     if (P.split_sa >= s_lo && P.split_sa <= s_hi) active = part_a(P.split_sa, std::true_type{});
     __syncthreads();
     if (tid == 0) ws[W::FLG] = active ? (double)P.split_sa : -1.0;
-  } else if (P.split_mode == 0) {
+   } else {
+    if (tid == 0) ws[W::FLG] = -1.0;
+   }
+  } else {
     for (long s = s_hi; s >= s_lo; --s) {
       if (!part_a(s, std::false_type{})) continue;
       nan_seen = mfma_gain_phase<d, q>(ws, lds) || nan_seen;
       part_c(s, std::false_type{});
     }
-  } else {
-    if (tid == 0) ws[W::FLG] = -1.0;
   }
   if (staged) {
     for (int k = tid; k < D; k += nth) ws[W::MSV + k] = ms_[k];
