@@ -529,13 +529,10 @@ struct LaunchTeamSmoothSweeps {
   void operator()() {
     using W = MfmaSmoothWs<d, q + 1>;
     constexpr size_t lds_bytes = ((size_t)(W::DPB * (W::DPB + 1) / 2) * mf::kB * 17 + 272) * sizeof(double);
-    static bool attr_set = false;  // (per instantiation)
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)rts_smooth_sweeps_kernel<d, q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
-        rc = -6;
-        return;
-      }
-      attr_set = true;
+    // (set at every launch: the attribute belongs to the current device, and a group of contexts spans several)
+    if (hipFuncSetAttribute((const void*)rts_smooth_sweeps_kernel<d, q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+      rc = -6;
+      return;
     }
     hipLaunchKernelGGL((rts_smooth_sweeps_kernel<d, q>), dim3(team_grid(P.N)), dim3(64 * W::DPB), lds_bytes, s, P, ws);
   }
