@@ -8,6 +8,7 @@
 #include "smooth_team.h"
 #include "smooth_rows.h"
 #include "smooth_lane.h"
+#include "smooth_pair.h"
 #include "dense_lane.h"
 #include "sample_lane.h"
 #include "filter_team.h"
@@ -169,6 +170,28 @@ __global__ __launch_bounds__(kWave) void rts_smooth_lane_kernel(const SmoothPara
   long n_hi = P.n_save;
   if constexpr (ADAPT) n_hi = wave_uniform_max(valid ? (long)P.nsaved[i0 + threadIdx.x] : 0, valid);
   if (valid) smooth_lane_v2<d, q, ADAPT>(P, i0, threadIdx.x, xl, n_hi);
+}
+
+// Smoother, two lanes per trajectory (smooth_pair.h; even D <= 12, the large ensembles the lane kernel used to take): 32
+// trajectories per wavefront, the pair's LDS image 20 KB per wavefront, <= 256 registers -- two wavefronts per SIMD.
+// ODEF_SMOOTH_PAIR=0 falls back to the one-lane-per-trajectory kernel (A/B runs; read at every launch).
+constexpr int kPairTraj = kWave / 2;
+inline bool smooth_pair_enabled() {
+  const char* e = getenv("ODEF_SMOOTH_PAIR");
+  return !(e && e[0] == '0');
+}
+template <int d, int q, bool ADAPT>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2))) void rts_smooth_pair_kernel(const SmoothParams P) {
+  constexpr int D = d * (q + 1), TRI = D * (D + 1) / 2;
+  __shared__ double lds[TRI * kPairTraj];
+  const long i0 = (long)blockIdx.x * kPairTraj;
+  const unsigned t = threadIdx.x >> 1;
+  const long i = i0 + t;
+  const bool valid = i < P.N;
+  long n_hi = P.n_save;
+  if constexpr (ADAPT) n_hi = wave_uniform_max(valid ? (long)P.nsaved[i] : 0, valid);
+  const pr::PairLds img{lds, {t, t ^ 8u}, (threadIdx.x & 1u) ? (unsigned)kPairTraj : 0u};
+  if (valid) smooth_pair_traj<d, q, ADAPT>(P, i, i0, img, n_hi);
 }
 
 // Dense output: blockIdx.y = query time, one lane per trajectory (D <= 12).
@@ -596,6 +619,16 @@ struct LaunchSmooth {
     }
     bool lane_kernel = false;
     if constexpr (d * (q + 1) <= kSmoothLaneMaxD) lane_kernel = P.N >= smooth_lane_min_n();
+    if constexpr (d * (q + 1) <= kSmoothLaneMaxD && (d * (q + 1)) % 2 == 0) {
+      if (lane_kernel && smooth_pair_enabled()) {  // two lanes per trajectory, two wavefronts per SIMD
+        const unsigned grid = (unsigned)((P.N + kPairTraj - 1) / kPairTraj);
+        if (P.adaptive)
+          hipLaunchKernelGGL((rts_smooth_pair_kernel<d, q, true>), dim3(grid), dim3(kWave), 0, s, P);
+        else
+          hipLaunchKernelGGL((rts_smooth_pair_kernel<d, q, false>), dim3(grid), dim3(kWave), 0, s, P);
+        return;
+      }
+    }
     if constexpr (d * (q + 1) <= kSmoothLaneMaxD) {
       if (lane_kernel) {
         const unsigned grid = (unsigned)((P.N + kWave - 1) / kWave);

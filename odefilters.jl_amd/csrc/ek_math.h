@@ -271,19 +271,20 @@ struct NoTick {
 };
 // `tick()` is called at regular points of the arithmetic; the lagged record sink of the filter (ek_lane.h) uses it to
 // spread the stores of the previous record over the step.
-template <int d, int NB, class Tick = NoTick>
-__device__ inline void predict_cov_inplace(const PriorConsts& pc, double (&X)[d * NB * (d * NB + 1) / 2], double sigma2,
+// `T`: the scalar type of the covariance (double; the two-lanes-per-trajectory smoother's host emulation passes its pair type).
+template <int d, int NB, class T, class Tick = NoTick>
+__device__ inline void predict_cov_inplace(const PriorConsts& pc, T (&X)[d * NB * (d * NB + 1) / 2], T sigma2,
                                            Tick tick = Tick{}) {
   constexpr int D = d * NB;
 #pragma unroll
   for (int J = 0; J + 1 < NB; ++J) {
     // W_JJ = X_JJ + sum_j a_j X_jJ from the old cells (full d x d block, not symmetric)
-    double Wd[d][d];
+    T Wd[d][d];
 #pragma unroll
     for (int a = 0; a < d; ++a)
 #pragma unroll
       for (int b = 0; b < d; ++b) {
-        double t = X[symidx(J * d + a, J * d + b)];
+        T t = X[symidx(J * d + a, J * d + b)];
 #pragma unroll
         for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * X[symidx(j * d + a, J * d + b)];
         Wd[a][b] = t;
@@ -296,7 +297,7 @@ __device__ inline void predict_cov_inplace(const PriorConsts& pc, double (&X)[d 
 #pragma unroll
       for (int c = 0; c < D; ++c) {
         if (c / d == J) continue;
-        double t = X[symidx(J * d + a, c)];
+        T t = X[symidx(J * d + a, c)];
 #pragma unroll
         for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * X[symidx(j * d + a, c)];
         X[symidx(J * d + a, c)] = t;
@@ -307,7 +308,7 @@ __device__ inline void predict_cov_inplace(const PriorConsts& pc, double (&X)[d 
     for (int a = 0; a < d; ++a)
 #pragma unroll
       for (int b = 0; b <= a; ++b) {
-        double t = Wd[a][b];
+        T t = Wd[a][b];
 #pragma unroll
         for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * X[symidx(J * d + a, j * d + b)];
         X[tri(J * d + a, J * d + b)] = t;
