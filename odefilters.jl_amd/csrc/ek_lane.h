@@ -59,6 +59,11 @@ struct RowStore {
   size_t n;
   RowStore(double* base, size_t N, size_t /*rows*/, unsigned lane) : p(base + lane), n(N) {}
   void put(double v) { *p = v; p += n; }
+  RowStore at_row(int row) const {  // (of a store that has not been advanced by put)
+    RowStore r = *this;
+    r.p = p + (size_t)row * n;
+    return r;
+  }
 };
 #else
 // Cache-policy bits of the record stores (gfx940+: bit 0 = sc0, bit 1 = nt, bit 4 = sc1).  The records are a pure
@@ -83,6 +88,42 @@ struct RowStore {
                                     // (ODEF_ROWSTORE_FREE_OFFSET: run-time compiled kernels of large state dimension,
                                     // where pinning it to an SGPR makes the register allocator give up)
 #endif
+  }
+  // a store positioned at field row `row` of the same record (one scalar multiply; put() then walks on from there)
+  __device__ RowStore at_row(int row) const {
+    RowStore r = *this;
+    r.soff = (unsigned)row * step;
+    return r;
+  }
+};
+#endif
+
+// Row load, the mirror image of RowStore: consecutive rows of one record field, every lane its own column; the row
+// offset is a running SGPR, so a record is read with no per-access VALU address arithmetic.
+#ifdef ODEF_HOST_EMUL
+struct RowLoad {
+  const double* p;
+  size_t n;
+  RowLoad(const double* base, size_t N, size_t /*rows*/, unsigned lane) : p(base + lane), n(N) {}
+  double get() {
+    const double v = *p;
+    p += n;
+    return v;
+  }
+};
+#else
+struct RowLoad {
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned voff, soff, step;
+  __device__ RowLoad(const double* base, size_t N, size_t rows, unsigned lane)
+      : rs(__builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(rows * N * sizeof(double)), 0x00020000)),
+        voff(lane * 8u), soff(0u), step((unsigned)(N * sizeof(double))) {}
+  __device__ double get() {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    soff += step;
+    asm volatile("" : "+s"(soff));
+    return __builtin_bit_cast(double, r);
   }
 };
 #endif

@@ -31,23 +31,26 @@ __device__ inline void two_sided_inverse(double (&S)[D * (D + 1) / 2], const dou
     const double inv = dinv[k];  // 1 / L_kk from the factorisation (0 for a zeroed column)
     const double tkk = S[tri(k, k)] * inv * inv;
     S[tri(k, k)] = tkk;
+    const double htkk = -0.5 * tkk;
 #pragma unroll
     for (int j = 0; j < k; ++j) S[tri(k, j)] *= inv;
     double b[D];
 #pragma unroll
     for (int i = k + 1; i < D; ++i) {
-      const double a = S[tri(i, k)] * inv;
       const double lik = L[tri(i, k)];
-      b[i] = a - 0.5 * lik * tkk;
+      b[i] = __builtin_fma(lik, htkk, S[tri(i, k)] * inv);
 #pragma unroll
-      for (int j = 0; j < k; ++j) S[tri(i, j)] -= lik * S[tri(k, j)];
+      for (int j = 0; j < k; ++j) S[tri(i, j)] = __builtin_fma(-lik, S[tri(k, j)], S[tri(i, j)]);
     }
+    // (two fused multiply-adds per entry: written as `S -= lik * b[j] + ljk * b[i]` the compiler must keep the rounding of
+    // the inner sum, i.e. a multiply, an FMA and an add -- 286 instructions more per step at D = 12)
 #pragma unroll
     for (int i = k + 1; i < D; ++i) {
       const double lik = L[tri(i, k)];
 #pragma unroll
-      for (int j = k + 1; j <= i; ++j) S[tri(i, j)] -= lik * b[j] + L[tri(j, k)] * b[i];
-      S[tri(i, k)] = b[i] - 0.5 * lik * tkk;
+      for (int j = k + 1; j <= i; ++j)
+        S[tri(i, j)] = __builtin_fma(-L[tri(j, k)], b[i], __builtin_fma(-lik, b[j], S[tri(i, j)]));
+      S[tri(i, k)] = __builtin_fma(lik, htkk, b[i]);
     }
     ODEF_SCHED_FENCE();
   });
@@ -222,54 +225,165 @@ __device__ inline long wave_uniform_max(long v, bool valid) {
 #endif
 }
 
+// ---- explicit register discipline of the smoother loop ------------------------------------------------------------------
+// A step needs three packed D x D matrices alive (78 doubles each at D = 12): the filter covariance X (read-only, in
+// lane-private LDS), the factor L of the predicted covariance, and M -> Z -> W; the smoothed covariance carried to the
+// next step takes over from L once that is dead.  Two matrices in registers are 312 of the 256 architectural VGPRs, so
+// one of them has to sit in the AGPR half of the lane's 512 registers -- which VALU instructions cannot address: every
+// visit costs a v_accvgpr_read/write per 32 bits.  Left to the register allocator this was 2 750 such moves per step, a
+// quarter of the step's issue slots (profiles/r02_isa_counts.txt): it cannot know that the two-sided transforms rewrite
+// all of S once per pivot but read only ONE COLUMN of L per pivot.  Handing the allocator AGPR-constrained values
+// (inline assembly, "a" constraints) did not work either: it could not pack the ~700 short live ranges into 256
+// registers and spilled AGPRs to scratch.  So the AGPR half is used as a hand-managed register FILE with static slots:
+//   TRI slots               one packed matrix: carried S^s_+ (raw)  ->  M = P S^s_+ P - B (across the Cholesky
+//                           factorisation)  ->  L (across the two-sided transforms, read one column per pivot)  ->  the
+//                           new S^s, entry by entry as it is produced
+//   D slots                 1 / L_kk         D slots   carried m^s_+
+// and everything the VALU works on stays below 256 VGPRs, so that the compiler never touches an AGPR itself --
+// tests/test_build_hygiene.py checks exactly that on the ISA of this kernel (every AGPR reference inside these
+// helpers' assembly).  1 160 moves per step instead of 2 750.  Host emulation: the file is a plain array.
+#ifdef ODEF_HOST_EMUL
+inline double* agpr_file() {
+  static thread_local double f[256];
+  return f;
+}
+template <int R>
+inline void aput(double v) { agpr_file()[R] = v; }
+template <int R>
+inline double aget() { return agpr_file()[R]; }
+inline void agpr_file_claim() {}
+#else
+template <int R>
+__device__ __attribute__((always_inline)) inline void aput(double v) {
+  static_assert(R >= 0 && R < 128, "a lane has 256 AGPRs = 128 doubles");
+  asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(__double2loint(v)), "n"(2 * R));
+  asm volatile("v_accvgpr_write_b32 a[%1], %0" ::"v"(__double2hiint(v)), "n"(2 * R + 1));
+}
+template <int R>
+__device__ __attribute__((always_inline)) inline double aget() {
+  static_assert(R >= 0 && R < 128, "a lane has 256 AGPRs = 128 doubles");
+  int lo, hi;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(lo) : "n"(2 * R));
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(hi) : "n"(2 * R + 1));
+  return __hiloint2double(hi, lo);
+}
+// Tells the compiler that the kernel uses the whole AGPR file (the kernel descriptor then allocates it).
+__device__ __attribute__((always_inline)) inline void agpr_file_claim() { asm volatile("" ::: "a255"); }
+#endif
+
+// Pins the values of an array at this point of the program: an empty volatile assembly statement per element that
+// "reads and writes" it.  __builtin_amdgcn_sched_barrier only stops the machine scheduler; instruction selection
+// orders the PURE arithmetic of a basic block by itself and let the Cholesky factorisation start above the statements
+// that still needed the unfactored matrix -- both generations of the matrix alive, the compiler reaching for AGPRs.
+// Arithmetic on pinned values cannot be placed before the pin, and pins keep their order among themselves and with the
+// AGPR-file accesses.
+template <int n>
+__device__ __attribute__((always_inline)) inline void pin(double (&a)[n]) {
+#ifndef ODEF_HOST_EMUL
+#pragma unroll
+  for (int k = 0; k < n; ++k) asm volatile("" : "+v"(a[k]));
+#else
+  (void)a;
+#endif
+}
+
+// two_sided_inverse with the factor in the AGPR file (slots LS + tri(i, k), reciprocal pivots DS + k): column k of L is
+// fetched once per pivot and pass
+template <int D, int LS, int DS>
+__device__ inline void two_sided_inverse_parked(double (&S)[D * (D + 1) / 2]) {
+  static_for<0, D>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const double inv = aget<DS + k>();
+    double lc[D];
+    static_for<k + 1, D>([&](auto ic) { lc[decltype(ic)::value] = aget<LS + tri(decltype(ic)::value, k)>(); });
+    const double tkk = S[tri(k, k)] * inv * inv;
+    S[tri(k, k)] = tkk;
+    const double htkk = -0.5 * tkk;
+#pragma unroll
+    for (int j = 0; j < k; ++j) S[tri(k, j)] *= inv;
+    double b[D];
+#pragma unroll
+    for (int i = k + 1; i < D; ++i) {
+      b[i] = __builtin_fma(lc[i], htkk, S[tri(i, k)] * inv);
+#pragma unroll
+      for (int j = 0; j < k; ++j) S[tri(i, j)] = __builtin_fma(-lc[i], S[tri(k, j)], S[tri(i, j)]);
+    }
+#pragma unroll
+    for (int i = k + 1; i < D; ++i) {
+#pragma unroll
+      for (int j = k + 1; j <= i; ++j) S[tri(i, j)] = __builtin_fma(-lc[j], b[i], __builtin_fma(-lc[i], b[j], S[tri(i, j)]));
+      S[tri(i, k)] = __builtin_fma(lc[i], htkk, b[i]);
+    }
+    pin(S);
+    ODEF_SCHED_FENCE();
+  });
+  static_for<0, D>([&](auto kc) {
+    constexpr int k = D - 1 - decltype(kc)::value;
+    const double inv = aget<DS + k>();
+    double lc[D];
+    static_for<k + 1, D>([&](auto ic) { lc[decltype(ic)::value] = aget<LS + tri(decltype(ic)::value, k)>(); });
+    double t[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      double s = S[symidx(k, j)];
+#pragma unroll
+      for (int i = k + 1; i < D; ++i) s -= lc[i] * S[symidx(i, j)];
+      t[j] = s;
+    }
+    double tk = t[k];
+#pragma unroll
+    for (int i = k + 1; i < D; ++i) tk -= lc[i] * t[i];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+      if (j != k) S[symidx(k, j)] = t[j] * inv;
+    S[tri(k, k)] = tk * inv * inv;
+    pin(S);
+    ODEF_SCHED_FENCE();
+  });
+}
+
 // `n_hi`: wave-uniform upper bound of the record count of the lanes of this wavefront (fixed grid: n_save).
 // ADAPT: per-trajectory record counts and step sizes (adaptive solve); otherwise everything about the grid is
 // wave-uniform and comes from the host tables.
+// The smoothed moments of time s+1 are CARRIED on chip (un-preconditioned, exactly the values stored): every record is
+// read once and written once.  The record slot is wave-uniform: records are addressed through buffer descriptors
+// (RowLoad / RowStore: row offset in a running SGPR, lane * 8 in voffset), no per-access VALU address arithmetic.
+// (Rounds 1-2 walked 64-bit pointers: 273 v_lshl_add_u64 per step.)
 template <int d, int q, bool ADAPT>
 __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned lane, const LaneMem& xl, long n_hi) {
   constexpr int NB = q + 1, D = d * NB, TRI = D * (D + 1) / 2;
+  // AGPR-file slots: matrix, reciprocal pivots, carried mean -- at the TOP of the file: should the compiler ever park a value of
+  // its own in an AGPR it takes the lowest free one, and tests/test_build_hygiene.py fails the build if one of those reaches
+  // the slots used here
+  constexpr int MS = 128 - (TRI + 2 * D), DS = MS + TRI, VS = DS + D;
+  static_assert(MS >= 0, "the AGPR file holds 128 doubles");
+  agpr_file_claim();
   const long i = i0 + lane;
   const long n = ADAPT ? (long)P.nsaved[i] : P.n_save;
   const size_t N = (size_t)P.N;
   const PriorConsts& pc = P.pc;
-  // The smoothed moments of time s+1 are CARRIED in registers (un-preconditioned, exactly the values stored): every
-  // record is read once and written once.  (Until round 2 the covariance was re-read from the record written one
-  // iteration earlier, 1.5 x the algorithmic traffic: profiles/r01_smoother_lane_pmc.json.)
-  double ms[D], Sn[TRI];
   for (int w = 0; w < 2; ++w) {  // first and last record are copied (src/smoothing.jl:11)
     const long s = w == 0 ? 0 : n - 1;
-    {
-      const double* src = P.cov + ((size_t)s * TRI) * N + i;
+    double c[TRI], m[D];
+    const double* src = P.cov + ((size_t)s * TRI) * N + i;
 #pragma unroll
-      for (int k = 0; k < TRI; ++k) Sn[k] = src[(size_t)k * N];  // all loads in flight before the first store
+    for (int k = 0; k < TRI; ++k) c[k] = src[(size_t)k * N];  // all loads in flight before the first store
 #pragma unroll
-      for (int k = 0; k < D; ++k) ms[k] = P.mean[((size_t)s * D + k) * N + i];
-      ODEF_SCHED_FENCE();
-      double* dst = P.scov + ((size_t)s * TRI) * N + i;
+    for (int k = 0; k < D; ++k) m[k] = P.mean[((size_t)s * D + k) * N + i];
+    ODEF_SCHED_FENCE();
+    double* dst = P.scov + ((size_t)s * TRI) * N + i;
 #pragma unroll
-      for (int k = 0; k < TRI; ++k) dst[(size_t)k * N] = Sn[k];
+    for (int k = 0; k < TRI; ++k) dst[(size_t)k * N] = c[k];
 #pragma unroll
-      for (int k = 0; k < D; ++k) P.smean[((size_t)s * D + k) * N + i] = ms[k];
-    }
+    for (int k = 0; k < D; ++k) P.smean[((size_t)s * D + k) * N + i] = m[k];
+    // the last record starts the carried state (written on both passes: the second one stays)
+    static_for<0, TRI>([&](auto kc) { aput<MS + decltype(kc)::value>(c[decltype(kc)::value]); });
+    static_for<0, D>([&](auto kc) { aput<VS + decltype(kc)::value>(m[decltype(kc)::value]); });
   }
   bool nan_seen = false;
-  // The slot index walks the same value in every lane but is deliberately kept in a VGPR: with a scalar slot
-  // the compiler moves the record address arithmetic to the SALU (s_mul chains, SGPR spills, hazard nops in
-  // front of the loads) and the fixed-grid smoother measured 44 ms instead of 39 ms.  (Round 2 tried the other
-  // extreme as well -- wave-uniform row bases advanced by s_add_u32 / s_addc_u32 and raw buffer accesses with a
-  // constant lane offset: 616 fewer VALU address instructions, but as many scalar ones, and a lone wavefront per SIMD
-  // pays one issue slot for either kind: 36 -> 60 ms with the spills that came with it.)
-  long s_start = n_hi - 2;
-#ifndef ODEF_HOST_EMUL
-  {
-    int lo = (int)s_start;
-    asm volatile("" : "+v"(lo));
-    s_start = lo;
-  }
-#endif
-  for (long s = s_start; s >= 1; --s) {
+  for (long s = n_hi - 2; s >= 1; --s) {
     if constexpr (ADAPT) {
-      if (s > n - 2) continue;  // this trajectory has fewer records: it joins at its own last one (ms, Sn hold it)
+      if (s > n - 2) continue;  // this trajectory has fewer records: it joins at its own last one (the file holds it)
     }
     double h, pj[NB], pij[NB];
     if constexpr (ADAPT) {
@@ -282,40 +396,30 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
         val *= h;
       }
     } else {
-      h = P.hs[s];
-      const double* __restrict__ tab = P.ptab + (size_t)P.tab_idx[s] * kTabStride;
+      h = uniform_load(P.hs + s);
+      const GlobalTab tab{P.ptab + (size_t)uniform_load(P.tab_idx + s) * kTabStride};
 #pragma unroll
       for (int J = 0; J < NB; ++J) {
         pj[J] = tab[kTabPJ + J];
         pij[J] = tab[kTabPIJ + J];
       }
     }
+    RowStore sm(P.smean + ((size_t)s * D) * N + i0, N, D, lane), sc(P.scov + ((size_t)s * TRI) * N + i0, N, TRI, lane);
     if (h == 0.0) {  // src/smoothing.jl:13-16
-#pragma unroll
-      for (int k = 0; k < D; ++k) P.smean[((size_t)s * D + k) * N + i] = ms[k];
-#pragma unroll
-      for (int k = 0; k < TRI; ++k) P.scov[((size_t)s * TRI + k) * N + i] = Sn[k];
+      static_for<0, D>([&](auto kc) { sm.put(aget<VS + decltype(kc)::value>()); });
+      static_for<0, TRI>([&](auto kc) { sc.put(aget<MS + decltype(kc)::value>()); });
       continue;
     }
     const double sigma2 = P.diff[(size_t)(s + 1) * N + i];
-    // x_i and x_{i+1}^s in preconditioned coordinates (src/smoothing.jl:23-24)
-    // Phase 1: every load of the step in flight (raw values, no arithmetic in between: a spill reload between two
-    // loads would make the compiler wait for the first one -- scratch and global loads share vmcnt -- and serialise
-    // the memory latencies of the step).  Phase 2: scale.
-    double mt[D], B[TRI], Cs[TRI];
+    // x_i in preconditioned coordinates (src/smoothing.jl:23-24).  Every load of the step in flight first (raw values, no
+    // arithmetic in between), then the scaling.
+    double mt[D], B[TRI];
     {
-      const double* pc_ = P.cov + ((size_t)s * TRI) * N + i;
-      const double* pm_ = P.mean + ((size_t)s * D) * N + i;
+      RowLoad lc(P.cov + ((size_t)s * TRI) * N + i0, N, TRI, lane), lm(P.mean + ((size_t)s * D) * N + i0, N, D, lane);
 #pragma unroll
-      for (int k = 0; k < TRI; ++k) {
-        B[k] = *pc_;
-        pc_ += N;
-      }
+      for (int k = 0; k < TRI; ++k) B[k] = lc.get();
 #pragma unroll
-      for (int k = 0; k < D; ++k) {
-        mt[k] = *pm_;
-        pm_ += N;
-      }
+      for (int k = 0; k < D; ++k) mt[k] = lm.get();
     }
     ODEF_SCHED_FENCE();
 #pragma unroll
@@ -324,27 +428,148 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
     for (int a = 0; a < D; ++a)
 #pragma unroll
       for (int b = 0; b <= a; ++b) {
-        const double pp = pj[a / d] * pj[b / d];
-        const double x = B[tri(a, b)] * pp;
+        const double x = B[tri(a, b)] * (pj[a / d] * pj[b / d]);
         xl.set(tri(a, b), x);
         B[tri(a, b)] = x;
-        Cs[tri(a, b)] = Sn[tri(a, b)] * pp;
       }
-    double msn[D], msnew[D];
+    pin(B);
+    pin(mt);
+    // delta = P m^s_+ - A m~   (src/smoothing.jl:38,44)
+    double dl[D];
+    static_for<0, D>([&](auto kc) { dl[decltype(kc)::value] = aget<VS + decltype(kc)::value>(); });
 #pragma unroll
-    for (int k = 0; k < D; ++k) msn[k] = pj[k / d] * ms[k];
-    auto sink = [&](int k, double v) {
-      Sn[k] = v;
-      P.scov[((size_t)s * TRI + k) * N + i] = v;
-    };
-    rts_step_core<d, NB>(pc, pij, mt, B, Cs, msn, sigma2, xl, msnew, sink);
+    for (int J = 0; J < NB; ++J)
 #pragma unroll
-    for (int k = 0; k < D; ++k) ms[k] = msnew[k];
+      for (int a = 0; a < d; ++a) {
+        double t = mt[J * d + a];
+#pragma unroll
+        for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * mt[j * d + a];
+        dl[J * d + a] = pj[J] * dl[J * d + a] - t;
+      }
+    pin(dl);
+    ODEF_SCHED_FENCE();
+    predict_cov_inplace<d, NB>(pc, B, sigma2);  // src/smoothing.jl:38
+    pin(B);
+    ODEF_SCHED_FENCE();
+    // M = P S^s_+ P - S^- takes the place of S^s_+ in the file, across the factorisation
+    // (a few entries per batch: an FMA right behind the AGPR read it depends on costs a wait state each time)
+    constexpr int kMB = 6;
+    static_for<0, (TRI + kMB - 1) / kMB>([&](auto cc) {
+      constexpr int k0 = decltype(cc)::value * kMB, nk = (k0 + kMB <= TRI) ? kMB : TRI - k0;
+      double v[kMB];
+      static_for<0, nk>([&](auto jc) { v[decltype(jc)::value] = aget<MS + k0 + decltype(jc)::value>(); });
+      static_for<0, nk>([&](auto jc) {
+        constexpr int k = k0 + decltype(jc)::value;
+        constexpr int a = [] { int r = 0; while ((r + 1) * (r + 2) / 2 <= k) ++r; return r; }();
+        constexpr int b = k - a * (a + 1) / 2;
+        v[decltype(jc)::value] = __builtin_fma(v[decltype(jc)::value], pj[a / d] * pj[b / d], -B[k]);
+      });
+      static_for<0, nk>([&](auto jc) { aput<MS + k0 + decltype(jc)::value>(v[decltype(jc)::value]); });
+    });
+    pin(B);
+    ODEF_SCHED_FENCE();
+    int fixes = 0;
+    double dinv[D];  // 1 / L_kk (0 for a zeroed column): every later division by a pivot is a multiplication with these
+    chol_packed<D>(B, fixes, dinv);
+    pin(B);
+    pin(dinv);
+    ODEF_SCHED_FENCE();
+    // w = A' B^-1 delta ;  m^s = m + X w  (src/smoothing.jl:42-44)
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-      nan_seen = nan_seen || !(ms[k] == ms[k]);
-      P.smean[((size_t)s * D + k) * N + i] = ms[k];
+      double t = dl[k];
+#pragma unroll
+      for (int c = 0; c < k; ++c) t -= B[tri(k, c)] * dl[c];
+      dl[k] = t * dinv[k];
     }
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+      double t = dl[k];
+#pragma unroll
+      for (int c = k + 1; c < D; ++c) t -= B[tri(c, k)] * dl[c];
+      dl[k] = t * dinv[k];
+    }
+    static_for<0, D>([&](auto kc) { aput<DS + decltype(kc)::value>(dinv[decltype(kc)::value]); });
+#pragma unroll
+    for (int K = NB - 1; K >= 1; --K)  // w = A' (.) in place: block K takes the still-untouched blocks j < K
+#pragma unroll
+      for (int b = 0; b < d; ++b)
+#pragma unroll
+        for (int j = 0; j < K; ++j) dl[K * d + b] += pc.At[j][K] * dl[j * d + b];
+    // each entry of X is read once for the two mean components it feeds
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int c = 0; c <= a; ++c) {
+        const double x = xl.get(tri(a, c));
+        mt[a] += x * dl[c];
+        if (c != a) mt[c] += x * dl[a];
+      }
+    static_for<0, D>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      const double v = mt[k] * pij[k / d];  // un-precondition (src/smoothing.jl:26)
+      nan_seen = nan_seen || !(v == v);
+      sm.put(v);
+      aput<VS + k>(v);
+    });
+    ODEF_SCHED_FENCE();
+    // L out to the file, M in -- entry by entry through the same slot, S[k] taking over the register of L[k]
+    double S[TRI];
+    static_for<0, TRI>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      S[k] = aget<MS + k>();
+      aput<MS + k>(B[k]);
+    });
+    pin(S);
+    ODEF_SCHED_FENCE();
+    // Z = B^-1 M B^-1 ;  W = A' Z A
+    two_sided_inverse_parked<D, MS, DS>(S);
+    pin(S);
+    ODEF_SCHED_FENCE();
+    congruence_At_inplace<d, NB>(pc, S);
+    pin(S);
+    ODEF_SCHED_FENCE();
+    // S^s = X + X W X, TWO rows at a time: u = x_a W for both, then every column b of X is read once from LDS for the two
+    // results it feeds (648 instead of 1 080 LDS values per step at D = 12); stored, and put into the file for the next step,
+    // as it is produced
+    auto rows = [&](auto a0c, auto nrc) {
+      constexpr int a0 = decltype(a0c)::value, nr = decltype(nrc)::value;  // rows a0 .. a0 + nr - 1
+      double u[nr][D];
+#pragma unroll
+      for (int r = 0; r < nr; ++r) {
+        double xa[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) xa[c] = xl.get(symidx(a0 + r, c));
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          double t = 0.0;
+#pragma unroll
+          for (int k = 0; k < D; ++k) t += xa[k] * S[symidx(k, c)];
+          u[r][c] = t;
+        }
+      }
+      RowStore st[2] = {sc.at_row(tri(a0, 0)), sc.at_row(tri(a0 + nr - 1, 0))};  // (nr <= 2: the second one is unused for nr = 1)
+      static_for<0, a0 + nr>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        double col[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) col[k] = xl.get(symidx(k, b));
+        static_for<0, nr>([&](auto rc) {
+          constexpr int a = a0 + decltype(rc)::value;
+          if constexpr (b <= a) {
+            double t = col[a];
+#pragma unroll
+            for (int k = 0; k < D; ++k) t += u[a - a0][k] * col[k];
+            const double v = t * (pij[a / d] * pij[b / d]);
+            st[a - a0].put(v);
+            aput<MS + tri(a, b)>(v);
+          }
+        });
+      });
+      ODEF_SCHED_FENCE();
+    };
+    static_for<0, D / 2>([&](auto pc_) { rows(std::integral_constant<int, 2 * decltype(pc_)::value>{}, std::integral_constant<int, 2>{}); });
+    if constexpr (D % 2 == 1) rows(std::integral_constant<int, D - 1>{}, std::integral_constant<int, 1>{});
   }
   if (nan_seen) P.retcode[i] = 3;  // "NaNs after smoothing" (src/smoothing.jl:25)
 }
