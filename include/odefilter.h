@@ -223,6 +223,11 @@ int odef_synchronize(odef_ctx* ctx);
 /* Device time of the last filter (which=0) / smoother (which=1) launch, measured with
  * hipEvents on the launch stream; n_launches = kernels launched by that call. */
 int odef_kernel_time_ms(odef_ctx* ctx, int which, float* ms, int* n_launches);
+/* Name of the kernel that call launched (the dominant one of a multi-kernel pass), as a profiler prints it, e.g.
+ * "odef::ek_filter_fixed_kernel<odef::RhsLorenz63, 3, true, true, false>": which kernel serves a configuration depends on
+ * the state dimension and the ensemble size (crossovers in csrc/ek_kernels.h), and a benchmark line should name the kernel
+ * that ran, not re-derive those thresholds.  NUL-terminated into buf (truncated to n); "" before the first launch. */
+int odef_kernel_name(odef_ctx* ctx, int which, char* buf, size_t n);
 
 /* ---- ensemble sharded over the GPUs of one node, single host process -------------------------------
  * Trajectories are independent, so the ensemble is cut into contiguous blocks, one per device; nothing is exchanged

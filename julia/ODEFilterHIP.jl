@@ -38,6 +38,17 @@ end
 EnsembleHIP(rhs::Symbol; device=-1, devices=Int32[]) = EnsembleHIP(device, rhs, collect(Int32, devices))
 
 lasterr(ctx) = unsafe_string(ccall((:odef_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx))
+# which kernel the last filter (0) / smoother (1) pass launched, and its device time in ms
+function kernel_name(ctx, which::Integer)
+    buf = zeros(UInt8, 256)
+    GC.@preserve buf ccall((:odef_kernel_name, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{UInt8}, Csize_t), ctx, which, buf, length(buf))
+    return unsafe_string(pointer(buf))
+end
+function kernel_time_ms(ctx, which::Integer)
+    ms = Ref{Cfloat}(0); n = Ref{Cint}(0)
+    ccall((:odef_kernel_time_ms, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cfloat}, Ptr{Cint}), ctx, which, ms, n)
+    return ms[], n[]
+end
 check(rc, ctx) = rc == 0 || error("libodefilter_hip: " * lasterr(ctx))
 
 function fetch(ctx, field, ::Type{T}, dims...) where {T}

@@ -74,6 +74,7 @@ struct odef_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float ms[2] = {0.f, 0.f};
   int nl[2] = {0, 0};
+  char kname[2][192] = {"", ""};  // kernel of the last filter / smoother pass (odef_kernel_name)
   // odef_group runs its shards concurrently: with `defer` set, odef_solve_* / odef_smooth return after the launch and
   // complete_pending() does the wait + timing (pending: 1 = filter, 2 = smoother)
   bool defer = false;
@@ -617,6 +618,7 @@ int odef_solve_fixed(odef_ctx* c, const double* tgrid, int64_t n_t) {
       rc = launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 0, P, c->stream);
   }
   if (rc) return fail(c, "odef_solve_fixed: no kernel for rhs %d order %d", c->cfg.rhs_id, c->q);
+  std::snprintf(c->kname[0], sizeof c->kname[0], "%s", c->jit ? (P.everystep ? "odef_jit_fixed_every" : "odef_jit_fixed_final") : last_kernel());
   return finish_filter(c, 1);
 }
 
@@ -654,6 +656,7 @@ int odef_solve_adaptive(odef_ctx* c, double t1, double abstol, double reltol, do
                  : c->team_path ? launch_filter_pleiades_tiles(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 1)
                                 : launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 1, P, c->stream);
   if (rc) return fail(c, "odef_solve_adaptive: no kernel for rhs %d order %d", c->cfg.rhs_id, c->q);
+  std::snprintf(c->kname[0], sizeof c->kname[0], "%s", c->jit ? "odef_jit_adaptive" : last_kernel());
   return finish_filter(c, 1);
 }
 
@@ -716,6 +719,8 @@ int odef_smooth(odef_ctx* c) {
   } else
     rc = launch_smooth(c->d, c->q, S, c->stream);
   if (rc) return fail(c, "odef_smooth: no kernel for d %d order %d", c->d, c->q);
+  std::snprintf(c->kname[1], sizeof c->kname[1], "%s",
+                c->jit ? (c->jit->posterior ? (S.adaptive ? "odef_jit_smooth_adapt" : "odef_jit_smooth_fixed") : "odef_jit_smooth_rows") : last_kernel());
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   HIPCHK(c, hipGetLastError());
   c->nl[1] = 1;
@@ -914,6 +919,12 @@ int odef_synchronize(odef_ctx* c) {
   if (!c) return -1;
   if (set_device(c)) return -1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int odef_kernel_name(odef_ctx* c, int which, char* buf, size_t n) {
+  if (!c || which < 0 || which > 1 || !buf || n == 0) return -1;
+  std::snprintf(buf, n, "%s", c->kname[which]);
   return 0;
 }
 
@@ -1241,6 +1252,17 @@ int odef_group_get_gathered(odef_group* g, int32_t shard, double* host_dst /* [D
 }  // extern "C"
 
 namespace odef {
+namespace {
+thread_local char g_last_kernel[192] = "";
+}
+void note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(g_last_kernel, sizeof g_last_kernel, fmt, ap);
+  va_end(ap);
+}
+const char* last_kernel() { return g_last_kernel; }
+
 int launch_filter(int rhs, int q, int ek1, int adaptive, const FilterParams& P, hipStream_t s) {
   switch (rhs) {
     case ODEF_RHS_FHN: return launch_filter_fhn(q, ek1, adaptive, P, s);

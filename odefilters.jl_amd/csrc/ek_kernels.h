@@ -8,7 +8,6 @@
 #include "smooth_team.h"
 #include "smooth_rows.h"
 #include "smooth_lane.h"
-#include "smooth_pair.h"
 #include "dense_lane.h"
 #include "sample_lane.h"
 #include "filter_team.h"
@@ -172,28 +171,6 @@ __global__ __launch_bounds__(kWave) void rts_smooth_lane_kernel(const SmoothPara
   if (valid) smooth_lane_v2<d, q, ADAPT>(P, i0, threadIdx.x, xl, n_hi);
 }
 
-// Smoother, two lanes per trajectory (smooth_pair.h; even D <= 12, the large ensembles the lane kernel used to take): 32
-// trajectories per wavefront, the pair's LDS image 20 KB per wavefront, <= 256 registers -- two wavefronts per SIMD.
-// ODEF_SMOOTH_PAIR=0 falls back to the one-lane-per-trajectory kernel (A/B runs; read at every launch).
-constexpr int kPairTraj = kWave / 2;
-inline bool smooth_pair_enabled() {
-  const char* e = getenv("ODEF_SMOOTH_PAIR");
-  return !(e && e[0] == '0');
-}
-template <int d, int q, bool ADAPT>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(2))) void rts_smooth_pair_kernel(const SmoothParams P) {
-  constexpr int D = d * (q + 1), TRI = D * (D + 1) / 2;
-  __shared__ double lds[TRI * kPairTraj];
-  const long i0 = (long)blockIdx.x * kPairTraj;
-  const unsigned t = threadIdx.x >> 1;
-  const long i = i0 + t;
-  const bool valid = i < P.N;
-  long n_hi = P.n_save;
-  if constexpr (ADAPT) n_hi = wave_uniform_max(valid ? (long)P.nsaved[i] : 0, valid);
-  const pr::PairLds img{lds, {t, t ^ 8u}, (threadIdx.x & 1u) ? (unsigned)kPairTraj : 0u};
-  if (valid) smooth_pair_traj<d, q, ADAPT>(P, i, i0, img, n_hi);
-}
-
 // Dense output: blockIdx.y = query time, one lane per trajectory (D <= 12).
 template <int d, int q>
 __global__ __launch_bounds__(kWave) void dense_output_kernel(const DenseParams P) {
@@ -329,12 +306,14 @@ struct LaunchTilesFilter {
   template <class RHS, int q, bool EK1>
   void operator()() {
     if (!pleiades_filter_tiles()) {
+      note_kernel("odef::ek_filter_mfma%s_kernel<odef::%s, %d, %s>", adaptive ? "_adaptive" : "", RHS::name, q, tf(EK1));
       if (adaptive)
         hipLaunchKernelGGL((ek_filter_mfma_adaptive_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kMfBlock), 0, s, P);
       else
         hipLaunchKernelGGL((ek_filter_mfma_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kMfBlock), 0, s, P);
       return;
     }
+    note_kernel("odef::ek_filter_tiles%s_kernel<odef::%s, %d, %s>", adaptive ? "_adaptive" : "", RHS::name, q, tf(EK1));
     if (adaptive)
       hipLaunchKernelGGL((ek_filter_tiles_adaptive_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kTilesBlock), 0, s, P);
     else
@@ -347,6 +326,7 @@ struct LaunchTeamFilter {
   hipStream_t s;
   template <class RHS, int q, bool EK1>
   void operator()() {
+    note_kernel("odef::ek_filter_team_kernel<odef::%s, %d, %s>", RHS::name, q, tf(EK1));
     hipLaunchKernelGGL((ek_filter_team_kernel<RHS, q, EK1>), dim3((unsigned)TP.fp.N), dim3(kTeamBig), 0, s, TP);
   }
 };
@@ -566,6 +546,8 @@ struct LaunchTeamSmooth {
   hipStream_t s;
   template <int d, int q>
   void operator()() {
+    // (the workspace kernel of the pass: the dominant one also when the sweeps run in a kernel of their own)
+    note_kernel(pleiades_smooth_team() ? "odef::rts_smooth_team_kernel<%d, %d>" : P.split_mode != 0 ? "odef::rts_smooth_mfma_kernel<%d, %d, true>" : "odef::rts_smooth_mfma_kernel<%d, %d, false>", d, q);
     if (pleiades_smooth_team())
       hipLaunchKernelGGL((rts_smooth_team_kernel<d, q>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
     else if (P.split_mode != 0)
@@ -585,15 +567,25 @@ struct LaunchFilter {
     if constexpr (RHS::d * (q + 1) <= kRowsMaxD) {
       if (P.N < filter_rows_max_n()) {  // small ensemble: 16 lanes per trajectory
         const unsigned rgrid = rows_grid(P.N);
-        if (adaptive) hipLaunchKernelGGL((ek_filter_rows_adaptive_kernel<RHS, q, EK1>), dim3(rgrid), dim3(kRowsBlock), 0, s, P);
-        else if (P.everystep) hipLaunchKernelGGL((ek_filter_rows_kernel<RHS, q, EK1, true>), dim3(rgrid), dim3(kRowsBlock), 0, s, P);
-        else hipLaunchKernelGGL((ek_filter_rows_kernel<RHS, q, EK1, false>), dim3(rgrid), dim3(kRowsBlock), 0, s, P);
+        if (adaptive) {
+          note_kernel("odef::ek_filter_rows_adaptive_kernel<odef::%s, %d, %s>", RHS::name, q, tf(EK1));
+          hipLaunchKernelGGL((ek_filter_rows_adaptive_kernel<RHS, q, EK1>), dim3(rgrid), dim3(kRowsBlock), 0, s, P);
+        } else {
+          note_kernel("odef::ek_filter_rows_kernel<odef::%s, %d, %s, %s>", RHS::name, q, tf(EK1), tf(P.everystep));
+          if (P.everystep) hipLaunchKernelGGL((ek_filter_rows_kernel<RHS, q, EK1, true>), dim3(rgrid), dim3(kRowsBlock), 0, s, P);
+          else hipLaunchKernelGGL((ek_filter_rows_kernel<RHS, q, EK1, false>), dim3(rgrid), dim3(kRowsBlock), 0, s, P);
+        }
         return;
       }
     }
-    if (adaptive) hipLaunchKernelGGL((ek_filter_adaptive_kernel<RHS, q, EK1>), dim3(grid), dim3(kWave), 0, s, P);
-    else if (P.everystep && P.N < filter_lag_max_n())  // small ensemble: spread the record stores over the next step
-      hipLaunchKernelGGL((ek_filter_fixed_kernel<RHS, q, EK1, true, true>), dim3(grid), dim3(kWave), 0, s, P);
+    if (adaptive) {
+      note_kernel("odef::ek_filter_adaptive_kernel<odef::%s, %d, %s>", RHS::name, q, tf(EK1));
+      hipLaunchKernelGGL((ek_filter_adaptive_kernel<RHS, q, EK1>), dim3(grid), dim3(kWave), 0, s, P);
+      return;
+    }
+    const bool lag = P.everystep && P.N < filter_lag_max_n();  // small ensemble: spread the record stores over the next step
+    note_kernel("odef::ek_filter_fixed_kernel<odef::%s, %d, %s, %s, %s>", RHS::name, q, tf(EK1), tf(P.everystep), tf(lag));
+    if (lag) hipLaunchKernelGGL((ek_filter_fixed_kernel<RHS, q, EK1, true, true>), dim3(grid), dim3(kWave), 0, s, P);
     else if (P.everystep) hipLaunchKernelGGL((ek_filter_fixed_kernel<RHS, q, EK1, true>), dim3(grid), dim3(kWave), 0, s, P);
     else hipLaunchKernelGGL((ek_filter_fixed_kernel<RHS, q, EK1, false>), dim3(grid), dim3(kWave), 0, s, P);
   }
@@ -610,6 +602,7 @@ struct LaunchSmooth {
     if constexpr (d * (q + 1) <= kRowsMaxD) {
       if (P.N < smooth_rows_max_n()) {
         const unsigned rgrid = rows_grid(P.N);
+        note_kernel("odef::rts_smooth_bcast_kernel<%d, %d, %s>", d, q, tf(P.adaptive));
         if (P.adaptive)
           hipLaunchKernelGGL((rts_smooth_bcast_kernel<d, q, true>), dim3(rgrid), dim3(kRowsBlock), 0, s, P);
         else
@@ -619,19 +612,10 @@ struct LaunchSmooth {
     }
     bool lane_kernel = false;
     if constexpr (d * (q + 1) <= kSmoothLaneMaxD) lane_kernel = P.N >= smooth_lane_min_n();
-    if constexpr (d * (q + 1) <= kSmoothLaneMaxD && (d * (q + 1)) % 2 == 0) {
-      if (lane_kernel && smooth_pair_enabled()) {  // two lanes per trajectory, two wavefronts per SIMD
-        const unsigned grid = (unsigned)((P.N + kPairTraj - 1) / kPairTraj);
-        if (P.adaptive)
-          hipLaunchKernelGGL((rts_smooth_pair_kernel<d, q, true>), dim3(grid), dim3(kWave), 0, s, P);
-        else
-          hipLaunchKernelGGL((rts_smooth_pair_kernel<d, q, false>), dim3(grid), dim3(kWave), 0, s, P);
-        return;
-      }
-    }
     if constexpr (d * (q + 1) <= kSmoothLaneMaxD) {
       if (lane_kernel) {
         const unsigned grid = (unsigned)((P.N + kWave - 1) / kWave);
+        note_kernel("odef::rts_smooth_lane_kernel<%d, %d, %s>", d, q, tf(P.adaptive));
         if (P.adaptive)
           hipLaunchKernelGGL((rts_smooth_lane_kernel<d, q, true>), dim3(grid), dim3(kWave), 0, s, P);
         else
@@ -640,6 +624,7 @@ struct LaunchSmooth {
       }
     }
     const unsigned grid = (unsigned)((P.N + TPB - 1) / TPB);
+    note_kernel("odef::rts_smooth_kernel<%d, %d>", d, q);
     hipLaunchKernelGGL((rts_smooth_kernel<d, q>), dim3(grid), dim3(kWave), 0, s, P);
   }
 };

@@ -271,7 +271,7 @@ struct NoTick {
 };
 // `tick()` is called at regular points of the arithmetic; the lagged record sink of the filter (ek_lane.h) uses it to
 // spread the stores of the previous record over the step.
-// `T`: the scalar type of the covariance (double; the two-lanes-per-trajectory smoother's host emulation passes its pair type).
+// `T`: the scalar type of the covariance (double in every kernel; a host emulation of a multi-lane mapping may pass a vector type).
 template <int d, int NB, class T, class Tick = NoTick>
 __device__ inline void predict_cov_inplace(const PriorConsts& pc, T (&X)[d * NB * (d * NB + 1) / 2], T sigma2,
                                            Tick tick = Tick{}) {

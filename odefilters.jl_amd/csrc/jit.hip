@@ -9,6 +9,8 @@
 #include <elf.h>
 #include <hip/hip_runtime.h>
 
+#include <dirent.h>
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <spawn.h>
 #include <sys/wait.h>
@@ -42,8 +44,18 @@ std::mutex g_mu;
 std::vector<JitRhs> g_rhs;                                                      // id = kJitFirstId + index
 std::map<std::tuple<int, int, int, int>, std::unique_ptr<JitModule>> g_modules;  // (id, q, ek1, device)
 
+// Where the kernel headers live: $ODEFILTER_HIP_INCLUDE, else `../csrc` next to the directory this library was loaded
+// from (odefilters.jl_amd/lib/libodefilter_hip.so -> odefilters.jl_amd/csrc; found with dladdr, so a tree that was moved
+// or copied after the build still compiles user vector fields), else the directory of the build.
 std::string default_include_dir() {
   if (const char* e = getenv("ODEFILTER_HIP_INCLUDE")) return e;
+  Dl_info info;
+  if (dladdr((const void*)&default_include_dir, &info) && info.dli_fname) {
+    std::string lib = info.dli_fname;
+    const size_t slash = lib.rfind('/');
+    const std::string dir = (slash == std::string::npos ? std::string(".") : lib.substr(0, slash)) + "/../csrc";
+    if (access((dir + "/ek_lane.h").c_str(), R_OK) == 0) return dir;
+  }
 #ifdef ODEF_DEFAULT_CSRC
   return ODEF_DEFAULT_CSRC;
 #else
@@ -180,7 +192,63 @@ std::string out_of_line_device_functions(const std::string& co) {
   return names;
 }
 
-bool compile(const std::string& src, const std::string& include_dir, std::vector<char>& code, std::string& err) {
+// The lane smoother (smooth_lane.h) keeps a packed matrix and the carried mean in a HAND-MANAGED file at the top of the
+// lane's AGPRs, with register numbers fixed in inline assembly the compiler knows nothing about.  That is sound only while
+// the compiler's own AGPR use (it parks VGPRs there under pressure, lowest register first) stays below the file.  The
+// compiled-in kernels are checked at build time (tests/test_build_hygiene.py); a user's vector field changes nothing in
+// that kernel, but the check costs nothing, so the run-time compiled ones are checked on their ISA listing here:
+// returns the offending line, or "" when every AGPR reference of the odef_jit_smooth_* kernels outside the file's own
+// assembly lies below `first_slot`.
+std::string agpr_file_violation(const std::string& isa, int first_slot) {
+  bool in_kernel = false, in_asm = false;
+  size_t pos = 0;
+  while (pos < isa.size()) {
+    size_t eol = isa.find('\n', pos);
+    if (eol == std::string::npos) eol = isa.size();
+    const std::string line = isa.substr(pos, eol - pos);
+    pos = eol + 1;
+    if (line.rfind("odef_jit_smooth_", 0) == 0 && line.find(':') != std::string::npos) in_kernel = true;
+    else if (line.rfind(".Lfunc_end", 0) == 0) in_kernel = false;
+    if (!in_kernel) continue;
+    if (line.find("ASMSTART") != std::string::npos) { in_asm = true; continue; }
+    if (line.find("ASMEND") != std::string::npos) { in_asm = false; continue; }
+    if (in_asm) continue;
+    const std::string code = line.substr(0, line.find(';'));
+    for (size_t k = 0; k + 1 < code.size(); ++k) {
+      if (code[k] != 'a') continue;
+      if (k > 0 && (isalnum((unsigned char)code[k - 1]) || code[k - 1] == '_')) continue;
+      size_t j = k + 1;
+      if (code[j] == '[') ++j;
+      if (j >= code.size() || !isdigit((unsigned char)code[j])) continue;
+      // every number of a register or register range: a12, a[12], a[12:13], a[0xdc]
+      while (j < code.size() && (isalnum((unsigned char)code[j]) || code[j] == ':')) {
+        if (isdigit((unsigned char)code[j])) {
+          char* end = nullptr;
+          const long r = strtol(code.c_str() + j, &end, 0);
+          if (r >= first_slot) return line;
+          j = (size_t)(end - code.c_str());
+        } else {
+          ++j;
+        }
+      }
+    }
+  }
+  return "";
+}
+
+void remove_tree(const std::string& dir) {  // the compiler's temporaries (flat directory)
+  if (DIR* d = opendir(dir.c_str())) {
+    while (dirent* e = readdir(d)) {
+      const std::string n = e->d_name;
+      if (n != "." && n != "..") remove((dir + "/" + n).c_str());
+    }
+    closedir(d);
+  }
+  rmdir(dir.c_str());
+}
+
+// `agpr_first_slot` >= 0: the translation unit holds the lane smoother, whose AGPR file starts at that register (see above)
+bool compile(const std::string& src, const std::string& include_dir, std::vector<char>& code, std::string& err, int agpr_first_slot = -1) {
   char tmpl[] = "/tmp/odef_jit_XXXXXX";
   const char* dir = mkdtemp(tmpl);
   if (!dir) {
@@ -194,8 +262,7 @@ bool compile(const std::string& src, const std::string& include_dir, std::vector
     if (f && fclose(f) != 0) { /* reported below through `written` of the next open */ }
     if (!written) {
       err = "odef_rhs_compile: cannot write the generated source to " + srcp;
-      remove(srcp.c_str());
-      rmdir(dir);
+      remove_tree(base);
       return false;
     }
   }
@@ -209,7 +276,9 @@ bool compile(const std::string& src, const std::string& include_dir, std::vector
     posix_spawn_file_actions_init(&fa);
     posix_spawn_file_actions_addopen(&fa, 1, logp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
     posix_spawn_file_actions_adddup2(&fa, 1, 2);
-    const char* argv[] = {cc, "--offload-arch=gfx950", "-O3", "-std=c++20", "--genco", "-fno-crash-diagnostics", inc.c_str(), srcp.c_str(), "-o", outp.c_str(), nullptr};
+    // (--save-temps=obj: the ISA listing lands next to the output, for agpr_file_violation)
+    const char* argv[] = {cc, "--offload-arch=gfx950", "-O3", "-std=c++20", "--genco", "-fno-crash-diagnostics", agpr_first_slot >= 0 ? "--save-temps=obj" : "-DODEF_NO_LISTING",
+                          inc.c_str(), srcp.c_str(), "-o", outp.c_str(), nullptr};
     pid_t pid = 0;
     const int rc = posix_spawnp(&pid, cc, &fa, nullptr, const_cast<char* const*>(argv), environ);
     posix_spawn_file_actions_destroy(&fa);
@@ -231,11 +300,18 @@ bool compile(const std::string& src, const std::string& include_dir, std::vector
     const std::string stray = ok ? out_of_line_device_functions(co) : std::string();
     if (!stray.empty()) {
       err = "odef_rhs_compile: the compiler left device functions out of line (kernels with different register budgets would share them):\n" + stray.substr(0, 4000);
-      remove(srcp.c_str());
-      remove(outp.c_str());
-      remove(logp.c_str());
-      rmdir(dir);
+      remove_tree(base);
       return false;
+    }
+    if (ok && agpr_first_slot >= 0) {
+      const std::string isa = read_file(base + "/rhs-hip-amdgcn-amd-amdhsa-gfx950.s");
+      const std::string bad = isa.empty() ? std::string("(no ISA listing was produced)") : agpr_file_violation(isa, agpr_first_slot);
+      if (!bad.empty()) {
+        err = "odef_rhs_compile: the compiler's register allocation reaches the smoother's hand-managed AGPR file (first slot a" +
+              std::to_string(agpr_first_slot) + "): " + bad;
+        remove_tree(base);
+        return false;
+      }
     }
   }
   if (!ok) {
@@ -249,10 +325,7 @@ bool compile(const std::string& src, const std::string& include_dir, std::vector
       err += log.substr(0, 6000);
     }
   }
-  remove(srcp.c_str());
-  remove(outp.c_str());
-  remove(logp.c_str());
-  rmdir(dir);
+  remove_tree(base);
   return ok;
 }
 
@@ -306,7 +379,9 @@ JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& e
   m->posterior = r.d * (q + 1) <= 12;  // the lane smoother / dense output / sampler keep a packed matrix per lane in LDS
   m->rows_team = r.d * (q + 1) <= 16 ? 16 : 32;
   std::vector<char> code;
-  if (!compile(translation_unit(r, q, ek1, m->posterior), r.include_dir, code, err)) return nullptr;
+  const int D = r.d * (q + 1);
+  const int agpr_first_slot = m->posterior ? 2 * (128 - (D * (D + 1) / 2 + D)) : -1;  // MS of smooth_lane_v2 (smooth_lane.h)
+  if (!compile(translation_unit(r, q, ek1, m->posterior), r.include_dir, code, err, agpr_first_slot)) return nullptr;
   const hipError_t le = hipModuleLoadData(&m->mod, code.data());
   if (le != hipSuccess) {
     err = std::string("hipModuleLoadData failed for the run-time compiled vector field: ") + hipGetErrorString(le);

@@ -8,6 +8,11 @@
 #include "sample_lane.h"
 
 namespace odef {
+// The launchers say which kernel they picked (printf-style; the name a profiler prints); api.hip hands it out through
+// odef_kernel_name.  One slot per host thread: read back right after the launch call.
+void note_kernel(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+const char* last_kernel();
+inline const char* tf(bool b) { return b ? "true" : "false"; }
 // returns 0, or -2 when (rhs, q) is not instantiated
 int launch_filter(int rhs, int q, int ek1, int adaptive, const FilterParams& P, hipStream_t s);
 int launch_smooth(int d, int q, const SmoothParams& P, hipStream_t s);

@@ -228,6 +228,7 @@ struct HasWaveAssemble<RHS, std::enable_if_t<RHS::has_wave_assemble>> { static c
 
 struct RhsFHN {  // examples/fitzhughnagumo_animation.jl:8-16, README.md:36-44
   static constexpr int d = 2, np = 3, id = 0;
+  static constexpr const char* name = "RhsFHN";
   template <class T>
   __device__ static void f(const T (&u)[2], const double* p, T (&du)[2]) {
     const double a = p[0], b = p[1], c = p[2];
@@ -245,6 +246,7 @@ struct RhsFHN {  // examples/fitzhughnagumo_animation.jl:8-16, README.md:36-44
 
 struct RhsLorenz63 {
   static constexpr int d = 3, np = 3, id = 1;
+  static constexpr const char* name = "RhsLorenz63";
   template <class T>
   __device__ static void f(const T (&u)[3], const double* p, T (&du)[3]) {
     const double s = p[0], r = p[1], b = p[2];
@@ -262,6 +264,7 @@ struct RhsLorenz63 {
 
 struct RhsLotkaVolterra {
   static constexpr int d = 2, np = 4, id = 2;
+  static constexpr const char* name = "RhsLotkaVolterra";
   template <class T>
   __device__ static void f(const T (&u)[2], const double* p, T (&du)[2]) {
     const double a = p[0], b = p[1], c = p[2], dd = p[3];
@@ -279,6 +282,7 @@ struct RhsLotkaVolterra {
 
 struct RhsVanDerPol {  // test/specific_problems.jl:44-47
   static constexpr int d = 2, np = 1, id = 3;
+  static constexpr const char* name = "RhsVanDerPol";
   template <class T>
   __device__ static void f(const T (&u)[2], const double* p, T (&du)[2]) {
     const double mu = p[0];
@@ -296,6 +300,7 @@ struct RhsVanDerPol {  // test/specific_problems.jl:44-47
 
 struct RhsLinear {  // test/convergence.jl:9-14, test/state_init.jl:12-17
   static constexpr int d = 2, np = 2, id = 4;
+  static constexpr const char* name = "RhsLinear";
   template <class T>
   __device__ static void f(const T (&u)[2], const double* p, T (&du)[2]) {
     du[0] = p[0] * u[0];
@@ -314,6 +319,7 @@ struct RhsLinear {  // test/convergence.jl:9-14, test/state_init.jl:12-17
 //   x_i'' = sum_{j != i} m_j (x_j - x_i) / r_ij^3.   BASELINE.json config 4 (d = 28, D = 168 at order 5).
 struct RhsPleiades {
   static constexpr int d = 28, np = 0, id = 5;
+  static constexpr const char* name = "RhsPleiades";
   template <class T>
   __device__ static void f(const T (&u)[28], const double* /*p*/, T (&du)[28]) {
     for (int i = 0; i < 7; ++i) {

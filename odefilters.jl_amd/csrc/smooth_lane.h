@@ -235,13 +235,13 @@ __device__ inline long wave_uniform_max(long v, bool valid) {
 // all of S once per pivot but read only ONE COLUMN of L per pivot.  Handing the allocator AGPR-constrained values
 // (inline assembly, "a" constraints) did not work either: it could not pack the ~700 short live ranges into 256
 // registers and spilled AGPRs to scratch.  So the AGPR half is used as a hand-managed register FILE with static slots:
-//   TRI slots               one packed matrix: carried S^s_+ (raw)  ->  M = P S^s_+ P - B (across the Cholesky
-//                           factorisation)  ->  L (across the two-sided transforms, read one column per pivot)  ->  the
-//                           new S^s, entry by entry as it is produced
-//   D slots                 1 / L_kk         D slots   carried m^s_+
+//   TRI slots               one packed matrix: carried S^s_+ (raw, across the prediction and the Cholesky factorisation)
+//                           ->  L (across the two-sided transforms, read one column per pivot)  ->  the new S^s, entry
+//                           by entry as it is produced
+//   D slots                 carried m^s_+
 // and everything the VALU works on stays below 256 VGPRs, so that the compiler never touches an AGPR itself --
 // tests/test_build_hygiene.py checks exactly that on the ISA of this kernel (every AGPR reference inside these
-// helpers' assembly).  1 160 moves per step instead of 2 750.  Host emulation: the file is a plain array.
+// helpers' assembly).  850 moves per step instead of 2 750.  Host emulation: the file is a plain array.
 #ifdef ODEF_HOST_EMUL
 inline double* agpr_file() {
   static thread_local double f[256];
@@ -287,13 +287,13 @@ __device__ __attribute__((always_inline)) inline void pin(double (&a)[n]) {
 #endif
 }
 
-// two_sided_inverse with the factor in the AGPR file (slots LS + tri(i, k), reciprocal pivots DS + k): column k of L is
-// fetched once per pivot and pass
-template <int D, int LS, int DS>
+// two_sided_inverse with the factor in the AGPR file (slots LS + tri(i, k); the DIAGONAL slots hold 1 / L_kk, which is all
+// the transforms need of the diagonal): column k of L is fetched once per pivot and pass
+template <int D, int LS, bool MINUS_IDENTITY>
 __device__ inline void two_sided_inverse_parked(double (&S)[D * (D + 1) / 2]) {
   static_for<0, D>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    const double inv = aget<DS + k>();
+    const double inv = aget<LS + tri(k, k)>();
     double lc[D];
     static_for<k + 1, D>([&](auto ic) { lc[decltype(ic)::value] = aget<LS + tri(decltype(ic)::value, k)>(); });
     const double tkk = S[tri(k, k)] * inv * inv;
@@ -317,9 +317,18 @@ __device__ inline void two_sided_inverse_parked(double (&S)[D * (D + 1) / 2]) {
     pin(S);
     ODEF_SCHED_FENCE();
   });
+  if constexpr (MINUS_IDENTITY) {
+    // L^-1 (S - B) L^-T = L^-1 S L^-T - I: the difference S^s_+ - S^- the smoother needs is taken HERE, on the whitened
+    // matrix, so that S^s_+ - S^- never has to be formed (and parked) before the factorisation overwrites S^-.  A zeroed
+    // column of the factor (semi-definite S^-) has L^-1 taken as 0 there: its diagonal entry stays 0.
+    static_for<0, D>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      S[tri(k, k)] -= (aget<LS + tri(k, k)>() != 0.0) ? 1.0 : 0.0;
+    });
+  }
   static_for<0, D>([&](auto kc) {
     constexpr int k = D - 1 - decltype(kc)::value;
-    const double inv = aget<DS + k>();
+    const double inv = aget<LS + tri(k, k)>();
     double lc[D];
     static_for<k + 1, D>([&](auto ic) { lc[decltype(ic)::value] = aget<LS + tri(decltype(ic)::value, k)>(); });
     double t[D];
@@ -352,10 +361,10 @@ __device__ inline void two_sided_inverse_parked(double (&S)[D * (D + 1) / 2]) {
 template <int d, int q, bool ADAPT>
 __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned lane, const LaneMem& xl, long n_hi) {
   constexpr int NB = q + 1, D = d * NB, TRI = D * (D + 1) / 2;
-  // AGPR-file slots: matrix, reciprocal pivots, carried mean -- at the TOP of the file: should the compiler ever park a value of
+  // AGPR-file slots: matrix, carried mean -- at the TOP of the file: should the compiler ever park a value of
   // its own in an AGPR it takes the lowest free one, and tests/test_build_hygiene.py fails the build if one of those reaches
   // the slots used here
-  constexpr int MS = 128 - (TRI + 2 * D), DS = MS + TRI, VS = DS + D;
+  constexpr int MS = 128 - (TRI + D), VS = MS + TRI;
   static_assert(MS >= 0, "the AGPR file holds 128 doubles");
   agpr_file_claim();
   const long i = i0 + lane;
@@ -433,7 +442,6 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
         B[tri(a, b)] = x;
       }
     pin(B);
-    pin(mt);
     // delta = P m^s_+ - A m~   (src/smoothing.jl:38,44)
     double dl[D];
     static_for<0, D>([&](auto kc) { dl[decltype(kc)::value] = aget<VS + decltype(kc)::value>(); });
@@ -449,23 +457,6 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
     pin(dl);
     ODEF_SCHED_FENCE();
     predict_cov_inplace<d, NB>(pc, B, sigma2);  // src/smoothing.jl:38
-    pin(B);
-    ODEF_SCHED_FENCE();
-    // M = P S^s_+ P - S^- takes the place of S^s_+ in the file, across the factorisation
-    // (a few entries per batch: an FMA right behind the AGPR read it depends on costs a wait state each time)
-    constexpr int kMB = 6;
-    static_for<0, (TRI + kMB - 1) / kMB>([&](auto cc) {
-      constexpr int k0 = decltype(cc)::value * kMB, nk = (k0 + kMB <= TRI) ? kMB : TRI - k0;
-      double v[kMB];
-      static_for<0, nk>([&](auto jc) { v[decltype(jc)::value] = aget<MS + k0 + decltype(jc)::value>(); });
-      static_for<0, nk>([&](auto jc) {
-        constexpr int k = k0 + decltype(jc)::value;
-        constexpr int a = [] { int r = 0; while ((r + 1) * (r + 2) / 2 <= k) ++r; return r; }();
-        constexpr int b = k - a * (a + 1) / 2;
-        v[decltype(jc)::value] = __builtin_fma(v[decltype(jc)::value], pj[a / d] * pj[b / d], -B[k]);
-      });
-      static_for<0, nk>([&](auto jc) { aput<MS + k0 + decltype(jc)::value>(v[decltype(jc)::value]); });
-    });
     pin(B);
     ODEF_SCHED_FENCE();
     int fixes = 0;
@@ -489,7 +480,6 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
       for (int c = k + 1; c < D; ++c) t -= B[tri(c, k)] * dl[c];
       dl[k] = t * dinv[k];
     }
-    static_for<0, D>([&](auto kc) { aput<DS + decltype(kc)::value>(dinv[decltype(kc)::value]); });
 #pragma unroll
     for (int K = NB - 1; K >= 1; --K)  // w = A' (.) in place: block K takes the still-untouched blocks j < K
 #pragma unroll
@@ -513,17 +503,20 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
       aput<VS + k>(v);
     });
     ODEF_SCHED_FENCE();
-    // L out to the file, M in -- entry by entry through the same slot, S[k] taking over the register of L[k]
+    // L out to the file, P S^s_+ P in -- entry by entry through the same slot, S[k] taking over the register of L[k]
     double S[TRI];
     static_for<0, TRI>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
+      constexpr int a = [] { int r = 0; while ((r + 1) * (r + 2) / 2 <= k) ++r; return r; }();
+      constexpr int b = k - a * (a + 1) / 2;
       S[k] = aget<MS + k>();
-      aput<MS + k>(B[k]);
+      aput<MS + k>(a == b ? dinv[a] : B[k]);  // (the diagonal slot takes 1 / L_kk)
+      S[k] *= pj[a / d] * pj[b / d];
     });
     pin(S);
     ODEF_SCHED_FENCE();
-    // Z = B^-1 M B^-1 ;  W = A' Z A
-    two_sided_inverse_parked<D, MS, DS>(S);
+    // Z = B^-1 (S^s_+ - B) B^-1 ;  W = A' Z A
+    two_sided_inverse_parked<D, MS, true>(S);
     pin(S);
     ODEF_SCHED_FENCE();
     congruence_At_inplace<d, NB>(pc, S);

@@ -76,6 +76,7 @@ SYMBOLS = {
     "odef_bind_device": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
     "odef_synchronize": (C.c_int, [_vp]),
     "odef_kernel_time_ms": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "odef_kernel_name": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_size_t]),
     "odef_ibm": (C.c_int, [C.c_int, C.c_int, _dp, _dp]),
     "odef_preconditioner": (C.c_int, [C.c_int, C.c_int, C.c_double, _dp]),
     "odef_predict": (C.c_int, [C.c_int, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp]),
@@ -385,6 +386,12 @@ class Context:
 
     def bind_device(self, f: int, ptr: int, nbytes: int):
         self._chk(self.lib.odef_bind_device(self._h, f, _vp(ptr), nbytes))
+
+    def kernel_name(self, which=0) -> str:
+        """Name of the kernel the last filter (0) / smoother (1) pass launched, as a profiler prints it."""
+        buf = C.create_string_buffer(256)
+        self._chk(self.lib.odef_kernel_name(self._h, which, buf, 256))
+        return buf.value.decode()
 
     def kernel_time_ms(self, which=0):
         ms, n = C.c_float(), C.c_int()

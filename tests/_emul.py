@@ -87,7 +87,7 @@ def unpack_tril(c, D):
 
 def emul_solve(rhs_id, d, q, ek1, u0s, p, *, team=False, tgrid=None, adaptive=False, t0=0.0, t1=1.0, abstol=1e-6, reltol=1e-3,
                dt0=1e-2, max_save=4096, everystep=True, fixed_diffusion=False, want_loglik=True, smooth=False,
-               ctrl=None, dense_t=None, sample=None, dense_sample=None, pair_smoother=False):
+               ctrl=None, dense_t=None, sample=None, dense_sample=None):
     """u0s [N, d]; p [np] shared.  Returns dict of numpy arrays in the device layout transposed
     to trajectory-major: mean [N, n_save, D], cov [N, n_save, D, D] ..."""
     u0s = np.asarray(u0s, float)
@@ -139,9 +139,7 @@ def emul_solve(rhs_id, d, q, ek1, u0s, p, *, team=False, tgrid=None, adaptive=Fa
                loglik=loglik, naccept=ints[0], nreject=ints[1], nf=ints[2], njac=ints[3], nsaved=ints[4],
                retcode=ints[5], tgrid=tg)
     if smooth:
-        lib().emul_smoother_pair(int(bool(pair_smoother)))  # smooth_pair.h instead of smooth_lane.h (even D <= 12)
         rc = lib().emul_smooth(C.byref(a), d)
-        lib().emul_smoother_pair(0)
         assert rc == 0, rc
         out["smean"] = smean.transpose(2, 0, 1)
         out["scov"] = unpack_tril(scov.transpose(2, 0, 1), D)

@@ -7,7 +7,6 @@
 #include "../../odefilters.jl_amd/csrc/smooth_team.h"
 #include "../../odefilters.jl_amd/csrc/smooth_rows.h"
 #include "../../odefilters.jl_amd/csrc/smooth_lane.h"
-#include "../../odefilters.jl_amd/csrc/smooth_pair.h"
 #include "../../odefilters.jl_amd/csrc/dense_lane.h"
 #include "../../odefilters.jl_amd/csrc/filter_team.h"
 #include "../../odefilters.jl_amd/csrc/filter_tiles.h"
@@ -80,26 +79,11 @@ struct RunFilter {
     }
   }
 };
-static int g_pair_smoother = 0;  // emul_smoother_pair(1): the two-lanes-per-trajectory smoother (smooth_pair.h) for even D <= 12
-extern "C" void emul_smoother_pair(int on) { g_pair_smoother = on; }
 struct RunSmooth {
   const SmoothParams& P;
   int bcast_rows = 0;  // the DPP-broadcast row-team smoother (rows_smooth.h) instead of the default for this size
   template <int d, int q>
   void operator()() {
-    if constexpr (d * (q + 1) <= 12 && (d * (q + 1)) % 2 == 0) {
-      if (g_pair_smoother) {
-        constexpr int D = d * (q + 1);
-        std::vector<double> x(D * (D + 1) / 2);
-        for (long i = 0; i < P.N; ++i) {
-          if (P.adaptive)
-            smooth_pair_traj<d, q, true>(P, i, i, pr::PairLds{x.data()}, (long)P.nsaved[i]);
-          else
-            smooth_pair_traj<d, q, false>(P, i, i, pr::PairLds{x.data()}, P.n_save);
-        }
-        return;
-      }
-    }
     if constexpr (d * (q + 1) <= 16) {
       if (bcast_rows) {
         std::vector<double> ws(RowsSmoother<d, q, false>::kLdsDoubles);

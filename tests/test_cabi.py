@@ -20,7 +20,7 @@ def declared_symbols():
 def test_header_symbols_all_exported(pkg):
     lib = pkg.load_library()
     names = declared_symbols()
-    assert len(names) == 41  # 27 per-context entry points + 14 of the multi-GPU group (odef_shard_range, odef_group_*, odef_allgather)
+    assert len(names) == 42  # 28 per-context entry points + 14 of the multi-GPU group (odef_shard_range, odef_group_*, odef_allgather)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/odefilter.h but not exported"
     # and the Python binding table covers exactly the header

@@ -376,7 +376,7 @@ def test_row_team_adaptive_rejections_and_limits():
     np.testing.assert_allclose(rf["mean"][0][:nf, :3], fx.means(smoothed=False)[:, :3], rtol=1e-7)
 
 
-@pytest.mark.parametrize("kernel", ["lane", "lagged", "rows", "pair"])
+@pytest.mark.parametrize("kernel", ["lane", "lagged", "rows"])
 def test_zero_pivots_and_zero_reflector_norms(kernel):
     """The Cholesky-failure branch of the reference (src/filtering.jl:38-47) at its extreme: u' = 0 (linear field with
     p = 0) has z = 0 exactly, hence sigma^2 = 0 and a ZERO predicted covariance -- every Cholesky pivot and every
@@ -386,9 +386,9 @@ def test_zero_pivots_and_zero_reflector_norms(kernel):
     vf = orc.vector_field("linear")
     u0 = np.array([[0.75, -1.25], [2.0, 3.0]])
     tg = np.arange(17) * 2.0**-6
-    ev = {"lane": True, "lagged": 2, "rows": 3, "pair": True}[kernel]
+    ev = {"lane": True, "lagged": 2, "rows": 3}[kernel]
     for q in (1, 3):
-        r = E.emul_solve(vf.rhs_id, 2, q, True, u0, np.zeros(2), tgrid=tg, everystep=ev, smooth=True, pair_smoother=kernel == "pair")
+        r = E.emul_solve(vf.rhs_id, 2, q, True, u0, np.zeros(2), tgrid=tg, everystep=ev, smooth=True)
         assert (r["retcode"] == 0).all()
         np.testing.assert_array_equal(r["mean"][:, :, :2], np.broadcast_to(u0[:, None, :], (2, 17, 2)))
         assert np.all(r["mean"][:, :, 2:] == 0.0) and np.all(r["cov"] == 0.0) and np.all(r["diff"] == 0.0)
@@ -396,67 +396,19 @@ def test_zero_pivots_and_zero_reflector_norms(kernel):
         assert np.all(r["scov"] == 0.0)
 
 
-# ---- two lanes per trajectory (smooth_pair.h) -----------------------------------------------------------------------
-
-PAIR_CASES = [c for c in CASES if (orc.vector_field(c[0]).d * (c[1].order + 1)) % 2 == 0 and orc.vector_field(c[0]).d * (c[1].order + 1) <= 12]
-
-
-@pytest.mark.parametrize("rhs,alg,dt,tspan", PAIR_CASES, ids=[f"{c[0]}-{c[1].kind}{c[1].order}" for c in PAIR_CASES])
-def test_pair_smoother_fixed_grid(rhs, alg, dt, tspan):
-    """smooth_pair.h (even D <= 12) against the oracle, and against the one-lane-per-trajectory smoother on the same records."""
-    vf = orc.vector_field(rhs)
-    base, nm, nc = P.oracle_noise(vf, alg, vf.u0, dict(tspan=tspan, dt=dt), True)
-    u0s = np.stack([vf.u0, vf.u0 * (1 + 1e-3), vf.u0 * (1 - 2e-3)])
-    kw = dict(tgrid=np.array(base.t), smooth=True)
-    r = E.emul_solve(vf.rhs_id, vf.d, alg.order, alg.kind == "EK1", u0s, vf.p, pair_smoother=True, **kw)
-    P.check_against_oracle(r["smean"][0], r["scov"][0], base.means(smoothed=True), base.covs(smoothed=True), vf.d, nm, nc,
-                           f"pair smoother {rhs} {alg.kind}({alg.order})")
-    l = E.emul_solve(vf.rhs_id, vf.d, alg.order, alg.kind == "EK1", u0s, vf.p, **kw)
-    np.testing.assert_array_equal(r["mean"], l["mean"])  # same filter
-    for i in range(3):
-        np.testing.assert_allclose(r["smean"][i][:, : vf.d], l["smean"][i][:, : vf.d], rtol=1e-10)
-        assert P.cov_err(r["scov"][i], l["scov"][i]) <= max(1e-9, P.NOISE_FACTOR * nc)
-        np.testing.assert_array_equal(r["smean"][i][[0, -1]], r["mean"][i][[0, -1]])  # first / last record are copied
-        np.testing.assert_array_equal(r["scov"][i][[0, -1]], r["cov"][i][[0, -1]])
-    assert (r["retcode"] == 0).all()
-
-
-@pytest.mark.parametrize("dt0", [2.0**-9, 0.25])
-def test_pair_smoother_adaptive_records(dt0):
-    """One record per ATTEMPTED step (rejected attempts repeat the state at an unchanged time, src/smoothing.jl:13-16):
-    the pair smoother skips them, joins every trajectory at its own last record and agrees with the oracle."""
-    vf = orc.vector_field("lorenz63")
-    sol = orc.solve(vf, orc.EK1(order=3, smooth=True), adaptive=True, dt=dt0, tspan=(0.0, 0.5))
-    if dt0 > 0.1:
-        assert sol.nreject >= 1
-    u0s = np.stack([vf.u0, vf.u0 * (1 + 1e-2), vf.u0 * (1 - 3e-2)])  # different record counts per trajectory
-    kw = dict(adaptive=True, t0=0.0, t1=0.5, dt0=dt0, max_save=512, smooth=True)
-    r = E.emul_solve(vf.rhs_id, 3, 3, True, u0s, vf.p, pair_smoother=True, **kw)
-    l = E.emul_solve(vf.rhs_id, 3, 3, True, u0s, vf.p, **kw)
-    n = r["nsaved"][0]
-    assert n == len(sol.t) and (r["retcode"] == 0).all()
-    np.testing.assert_allclose(r["smean"][0][:n, :3], sol.means(smoothed=True)[:, :3], rtol=1e-7)
-    assert P.cov_err(r["scov"][0][:n], sol.covs(smoothed=True)) < 1e-5
-    for i in range(3):
-        ni = r["nsaved"][i]
-        np.testing.assert_allclose(r["smean"][i][:ni, :3], l["smean"][i][:ni, :3], rtol=1e-9)
-        assert P.cov_err(r["scov"][i][:ni], l["scov"][i][:ni]) < 1e-6
-
-
 # ---- against EXACT evaluations of the reference algorithm (tests/golden/make_exact.py) --------------------------------
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("kernel", ["lane", "rows", "pair"])
+@pytest.mark.parametrize("kernel", ["lane", "rows"])
 def test_lorenz_1024_steps_against_50_digit_evaluation(kernel):
     """BASELINE configs 2/3 (trajectory 0, all 1 024 steps), filter and smoother: the kernels' arithmetic (run on the host)
     is as close to the 50-digit mpmath evaluation of the reference algorithm as the float64 oracle is, block by block."""
     fx = np.load(os.path.join(GOLD, "exact_lorenz_mp.npz"))
     vf = orc.vector_field("lorenz63")
     tg = np.arange(int(fx["nsteps"]) + 1) * float(fx["dt"])
-    r = E.emul_solve(vf.rhs_id, 3, 3, True, fx["u0"][None, :], vf.p, tgrid=tg, everystep={"lane": True, "rows": 3, "pair": True}[kernel], smooth=True,
-                     pair_smoother=kernel == "pair")  # pair: the lane filter + the two-lanes-per-trajectory smoother (smooth_pair.h)
+    r = E.emul_solve(vf.rhs_id, 3, 3, True, fx["u0"][None, :], vf.p, tgrid=tg, everystep={"lane": True, "rows": 3}[kernel], smooth=True)
     P.check_against_exact(r["mean"][0], r["cov"][0], fx["mean_filt"], fx["cov_filt"], fx["oracle_block_err_filt"],
                           fx["oracle_cov_err_filt"], 3, f"{kernel} filter")
     P.check_against_exact(r["smean"][0], r["scov"][0], fx["mean_smooth"], fx["cov_smooth"], fx["oracle_block_err_smooth"],

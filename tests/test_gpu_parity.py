@@ -141,20 +141,19 @@ def test_row_team_filter_equals_lane_filter(pkg, monkeypatch):
 
 @pytest.mark.parametrize("adaptive", [False, True])
 def test_both_small_state_smoothers_against_oracle(pkg, adaptive, monkeypatch):
-    """D <= 12 has four smoother kernels, chosen by ensemble size (csrc/ek_kernels.h LaunchSmooth): DPP row teams for small
-    ensembles, LDS row teams, one lane per trajectory, and -- even D, large ensembles, the default there -- two lanes per
-    trajectory (smooth_pair.h).  The environment switches the launcher reads at every launch force each in turn."""
+    """D <= 12 has three smoother kernels, chosen by ensemble size (csrc/ek_kernels.h LaunchSmooth): DPP row teams for small
+    ensembles, LDS row teams, one lane per trajectory for large ones.  The environment switches the launcher reads at every
+    launch force each in turn."""
     vf = orc.vector_field("lorenz63")
     N, t1 = 130, 0.5
     ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz63", vf.u0, (0.0, t1), vf.p), perturb_scale=1e-2)
     u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
     kw = dict(dt=2.0**-9, adaptive=True, max_steps=256) if adaptive else dict(dt=2.0**-7, adaptive=False)
     sols = {}
-    kernels = {"pair": ("0", "1", "1"), "lane": ("0", "1", "0"), "rows": ("0", "1000000000", "1"), "bcast": ("1000000000", "1", "1")}
-    for name, (rows_max, lane_min, pair) in kernels.items():
+    kernels = {"lane": ("0", "1"), "rows": ("0", "1000000000"), "bcast": ("1000000000", "1")}
+    for name, (rows_max, lane_min) in kernels.items():
         monkeypatch.setenv("ODEF_SMOOTH_ROWS_MAX_N", rows_max)
         monkeypatch.setenv("ODEF_SMOOTH_LANE_MIN_N", lane_min)
-        monkeypatch.setenv("ODEF_SMOOTH_PAIR", pair)
         sols[name] = pkg.solve(ens, pkg.EK1(order=3), pkg.EnsembleHIP(), trajectories=N, **kw)
         assert sols[name].retcode == ["Success"] * N
         _ = sols[name].x_smooth_mean()  # fetch while the override is in place (lazy accessors)
@@ -166,34 +165,34 @@ def test_both_small_state_smoothers_against_oracle(pkg, adaptive, monkeypatch):
             m, c = sols[name].x_smooth_mean()[i][:n], sols[name].x_smooth_cov()[i][:n]
             np.testing.assert_allclose(m[:, :3], ref.means(smoothed=True)[:, :3], rtol=1e-7 if adaptive else 1e-10, err_msg=name)
             assert P.cov_err(c, ref.covs(smoothed=True)) < 1e-5, name
-    for name in ("pair", "rows", "bcast"):
+    for name in ("rows", "bcast"):
         np.testing.assert_allclose(sols[name].x_smooth_mean()[..., :3], sols["lane"].x_smooth_mean()[..., :3], rtol=1e-9, atol=1e-12, err_msg=name)
 
 
-@pytest.mark.parametrize("rhs,order", [("fhn", 1), ("fhn", 3), ("lotka_volterra", 2), ("vanderpol", 4), ("lotka_volterra", 5), ("lorenz63", 1)])
-def test_pair_smoother_other_state_dimensions(pkg, rhs, order, monkeypatch):
-    """smooth_pair.h at D = 4, 6, 8, 10, 12 (d = 2 and 3), an ensemble that does not fill its last wavefront: against the
-    oracle and against the one-lane-per-trajectory kernel on the same filter records."""
+@pytest.mark.parametrize("rhs,order", [("fhn", 1), ("fhn", 3), ("lotka_volterra", 2), ("vanderpol", 4), ("lotka_volterra", 5), ("lorenz63", 1), ("lorenz63", 2)])
+def test_lane_smoother_other_state_dimensions(pkg, rhs, order, monkeypatch):
+    """The one-lane-per-trajectory smoother (smooth_lane.h: hand-managed AGPR file, two result rows per pass) at D = 4, 6, 8,
+    9, 10, 12 (d = 2 and 3; odd D has an unpaired last row), an ensemble that does not fill its last wavefront: against
+    the oracle and against the LDS row-team smoother on the same filter records."""
     vf = orc.vector_field(rhs)
     N, dt, t1 = 77, 2.0**-7, 0.5
     monkeypatch.setenv("ODEF_SMOOTH_ROWS_MAX_N", "0")
-    monkeypatch.setenv("ODEF_SMOOTH_LANE_MIN_N", "1")
     ens = pkg.EnsembleProblem(pkg.ODEProblem(rhs, vf.u0, (0.0, t1), vf.p), perturb_scale=1e-2)
     u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
     out = {}
-    for name, flag in (("pair", "1"), ("lane", "0")):
-        monkeypatch.setenv("ODEF_SMOOTH_PAIR", flag)
+    for name, lane_min in (("lane", "1"), ("rows", "1000000000")):
+        monkeypatch.setenv("ODEF_SMOOTH_LANE_MIN_N", lane_min)
         sol = pkg.solve(ens, pkg.EK1(order=order), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
         assert sol.retcode == ["Success"] * N
         out[name] = (sol.x_smooth_mean(), sol.x_smooth_cov(), sol.x_filt_mean(), sol.x_filt_cov())
-    pm, pc, fm, fc = out["pair"]
-    lm, lc = out["lane"][:2]
+    pm, pc, fm, fc = out["lane"]
+    lm = out["rows"][0]
     np.testing.assert_array_equal(pm[:, [0, -1]], fm[:, [0, -1]])  # first and last record are copied (src/smoothing.jl:11)
     np.testing.assert_array_equal(pc[:, [0, -1]], fc[:, [0, -1]])
     for i in (0, 31, 32, 76):
         alg = orc.EK1(order=order)
         base, nm, nc = P.oracle_noise(vf, alg, u0s[i], dict(tspan=(0.0, t1), dt=dt), True)
-        P.check_against_oracle(pm[i], pc[i], base.means(smoothed=True), base.covs(smoothed=True), vf.d, nm, nc, f"pair smoother {rhs}({order}) traj {i}")
+        P.check_against_oracle(pm[i], pc[i], base.means(smoothed=True), base.covs(smoothed=True), vf.d, nm, nc, f"lane smoother {rhs}({order}) traj {i}")
         np.testing.assert_allclose(pm[i][:, : vf.d], lm[i][:, : vf.d], rtol=1e-10)
 
 
@@ -1019,6 +1018,7 @@ def test_user_vector_field_equals_the_compiled_in_one(pkg, monkeypatch):
     row-team kernels, which agree to rounding only.)"""
     monkeypatch.setenv("ODEF_FILTER_ROWS_MAX_N", "0")
     monkeypatch.setenv("ODEF_SMOOTH_ROWS_MAX_N", "0")
+    monkeypatch.setenv("ODEF_SMOOTH_LANE_MIN_N", "1")  # (70 trajectories would otherwise go to the LDS row-team smoother)
     pkg.compile_rhs("UserLorenz", USER_LORENZ, 3, 3)
     vf = orc.vector_field("lorenz63")
     N = 70

@@ -56,7 +56,7 @@ def main():
             m = re.match(r"^(\.LBB\S+):", s)
             if m:
                 labels[m.group(1)] = len(instrs)
-                if "Loop Header" in s:
+                if "Loop Header" in s or "in Loop:" in s:  # (a rotated loop branches back to a block in front of its header)
                     headers.add(m.group(1))
             continue
         op = s.split()[0]
