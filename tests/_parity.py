@@ -97,3 +97,29 @@ def check_against_exact(mean, cov, exact_mean, exact_cov, oracle_block_err, orac
     ce = cov_err(cov, exact_cov)
     assert ce <= EXACT_FACTOR * float(oracle_cov_err), f"{what}: covariance error vs exact {ce:.2e} exceeds {EXACT_FACTOR} x the oracle's {float(oracle_cov_err):.2e}"
     return be, ce
+
+
+def check_against_exact_fixture(fx, k, mean_f, cov_f, mean_s, cov_s, d, what=""):
+    """tests/golden/exact_pleiades_*_smooth_ld.npz (make_exact.py: filter and smoother in extended precision, trajectories
+    fx["trajs"], covariances at ONE record each as packed lower triangles): trajectory number `k` of the fixture.  mean_* are
+    [n_save, D], cov_* [n_save, D, D] of the device.  The yardstick per derivative block / covariance is the float64 oracle's
+    own distance from the exact result, the LARGEST over the fixture's trajectories: where that arithmetic is rounding noise
+    (order 5 at dt = 2^-10: the first residuals are h^5-small, the oracle's diffusions up to 300x off) a single trajectory's
+    distance is a lottery ticket, not a scale."""
+    D = mean_f.shape[-1]
+    il = np.tril_indices(D)
+    out = {}
+    for name, mean, cov, rec in (("filt", mean_f, cov_f, int(fx["cov_record_filt"])), ("smooth", mean_s, cov_s, int(fx["cov_record_smooth"]))):
+        exact_mean = fx["mean_" + name][k]
+        be = block_err(mean, exact_mean, d)
+        assert be[0] <= U_RTOL, f"{what} {name}: posterior mean of the solution off by {be[0]:.2e} from the exact result"
+        tol = np.maximum(EXACT_FACTOR * fx["oracle_block_err_" + name].max(axis=0), 1e-15)
+        assert np.all(be <= tol), f"{what} {name}: block errors vs exact {be} exceed {EXACT_FACTOR} x the oracle's {fx['oracle_block_err_' + name].max(axis=0)}"
+        exact_cov = np.zeros((D, D))
+        exact_cov[il] = fx[f"cov_{name}_tril"][k]
+        exact_cov = exact_cov + np.tril(exact_cov, -1).T
+        ce = cov_err(cov[rec][None], exact_cov[None])
+        ctol = EXACT_FACTOR * float(fx["oracle_cov_err_" + name].max())
+        assert ce <= ctol, f"{what} {name}: covariance of record {rec} off by {ce:.2e} from the exact one, {EXACT_FACTOR} x the oracle's distance is {ctol:.2e}"
+        out[name] = (be, ce)
+    return out

@@ -13,6 +13,10 @@ exact result there).  So "the device agrees with the oracle to x" is the wrong q
                          filter, numpy longdouble (x87 extended, 64-bit mantissa = 2 048 x finer than float64: D = 168
                          is out of reach for mpmath in a build-container minute, and 11 extra bits are enough to rank
                          two float64 results)
+  exact_pleiades_{ek1q2,ek0q3,ek1q5,ek1q5_dt6}_smooth_ld.npz
+                         Pleiades, 12 steps, trajectories 0 and 4, filter AND RTS smoother (D = 84, 112, 168), longdouble: what
+                         the D = 168 kernels' parity tests are measured against (round 3; until then their tolerance was
+                         calibrated on the float64 oracle's own spread, and the order-5 covariances were not compared at all)
 
 and, next to them, the float64 oracle's distance from them per derivative block and for the covariance.  Any
 mathematically equivalent formulation gives the same exact result, so the recursion is written in the plain covariance
@@ -214,8 +218,10 @@ def pleiades_jac_ld(u):
     return J
 
 
-def filter_ld(vf, u0, q, dt, nsteps):
-    """Pleiades only (its f is written for any scalar type, its Jacobian is restated above in longdouble)."""
+def filter_ld(vf, u0, q, dt, nsteps, kind="EK1", with_smoother=False):
+    """Pleiades only (its f is written for any scalar type, its Jacobian is restated above in longdouble).  EK0 / EK1 filter and,
+    if asked, the RTS pass (src/smoothing.jl:4-63) over the same records, all in longdouble.  Returns float64 copies:
+    (means, covs) or (means, covs, smoothed means, smoothed covs, diffusions)."""
     ld = np.longdouble
     d, NB = vf.d, q + 1
     D = d * NB
@@ -240,16 +246,16 @@ def filter_ld(vf, u0, q, dt, nsteps):
     P = np.repeat(np.array([h ** (ld(j) - ld(q) - ld(0.5)) for j in range(NB)], dtype=ld), d)
     PI = ld(1) / P
     S_ = np.zeros((D, D), dtype=ld)
-    means, covs = [m.copy()], [S_.copy()]
+    means, covs, diffs = [m.copy()], [S_.copy()], []
     for n in range(nsteps):
         mt, X = P * m, S_ * np.outer(P, P)
         mp_ = A @ mt
         up = (PI * mp_)[:d]
         du = np.asarray(vf.f(list(up), None, 0.0), dtype=ld)
         z = (PI * mp_)[d:2 * d] - du
-        J = pleiades_jac_ld(up)
         H = np.zeros((d, D), dtype=ld)
-        H[:, :d] = -J * PI[:d][None, :]
+        if kind == "EK1":
+            H[:, :d] = -pleiades_jac_ld(up) * PI[:d][None, :]
         H[:, d:2 * d] = np.diag(PI[d:2 * d])
         W = H @ Q @ H.T
         s2 = (z @ solve_spd_ld(W, z[:, None])[:, 0]) / d
@@ -262,8 +268,53 @@ def filter_ld(vf, u0, q, dt, nsteps):
         Xf = IKH @ Xp @ IKH.T  # Joseph form (see lorenz_mp)
         Xf = (Xf + Xf.T) / 2
         m, S_ = PI * mf, Xf * np.outer(PI, PI)
-        means.append(m.copy()); covs.append(S_.copy())
-    return np.array(means).astype(np.float64), np.array(covs).astype(np.float64)
+        means.append(m.copy()); covs.append(S_.copy()); diffs.append(s2)
+    f64 = lambda a: np.array(a).astype(np.float64)  # noqa: E731
+    if not with_smoother:
+        return f64(means), f64(covs)
+    # RTS pass: x_i^s from x_i (filter) and x_{i+1}^s, G = X A' (A X A' + sigma_i^2 Q)^-1 in preconditioned coordinates;
+    # diffusions[i] belongs to the step t_i -> t_{i+1} (src/integrator_utils.jl:44)
+    sm, sc = [None] * (nsteps + 1), [None] * (nsteps + 1)
+    sm[nsteps], sc[nsteps] = means[nsteps], covs[nsteps]
+    sm[0], sc[0] = means[0], covs[0]
+    PP = np.outer(P, P)
+    for i in range(nsteps - 1, 0, -1):
+        mt, X = P * means[i], covs[i] * PP
+        B = A @ X @ A.T + diffs[i] * Q
+        B = (B + B.T) / 2
+        G = solve_spd_ld(B, A @ X).T  # X A' B^-1 (X, B symmetric)
+        ms_ = mt + G @ (P * sm[i + 1] - A @ mt)
+        Ss = X + G @ (sc[i + 1] * PP - B) @ G.T
+        Ss = (Ss + Ss.T) / 2
+        sm[i], sc[i] = PI * ms_, Ss * np.outer(PI, PI)
+    return f64(means), f64(covs), f64(sm), f64(sc), f64(diffs)
+
+
+def pleiades_fixture(q, kind, nsteps, dt, trajs=(0, 4)):
+    """Trajectories `trajs` of the Pleiades ensemble (positions perturbed by 1e-3): filter and smoother in
+    extended precision, and the float64 oracle's distance from them -- per derivative block for the means (all records) and
+    for the covariance at one record each: the LAST filter record and smoothed record 1 (the one the backward pass reaches
+    last), stored as packed lower triangles."""
+    vp = orc.vector_field("pleiades")
+    u0s = orc.ensemble_u0(vp.u0, max(trajs) + 1, 1e-3, n_perturbed=14)
+    D = 28 * (q + 1)
+    il = np.tril_indices(D)
+    out = dict(trajs=np.array(trajs), u0s=u0s[list(trajs)], dt=dt, nsteps=nsteps, order=q, ek1=int(kind == "EK1"),
+               cov_record_filt=nsteps, cov_record_smooth=1)
+    acc = {k: [] for k in ("mean_filt", "mean_smooth", "diffusions", "cov_filt_tril", "cov_smooth_tril", "oracle_block_err_filt",
+                           "oracle_block_err_smooth", "oracle_cov_err_filt", "oracle_cov_err_smooth", "oracle_diffusion_err")}
+    for i in trajs:
+        mf, cf, ms, cs, df = filter_ld(vp, u0s[i], q, dt, nsteps, kind=kind, with_smoother=True)
+        sol = orc.solve(vp, orc.Alg(kind, q, "dynamic", True), u0=u0s[i], tspan=(0.0, nsteps * dt), dt=dt)
+        acc["mean_filt"].append(mf); acc["mean_smooth"].append(ms); acc["diffusions"].append(df)
+        acc["cov_filt_tril"].append(cf[nsteps][il]); acc["cov_smooth_tril"].append(cs[1][il])
+        acc["oracle_block_err_filt"].append(block_err(sol.means(smoothed=False), mf, 28))
+        acc["oracle_block_err_smooth"].append(block_err(sol.means(smoothed=True), ms, 28))
+        acc["oracle_cov_err_filt"].append(cov_err(sol.covs(smoothed=False)[nsteps:nsteps + 1], cf[nsteps:nsteps + 1]))
+        acc["oracle_cov_err_smooth"].append(cov_err(sol.covs(smoothed=True)[1:2], cs[1:2]))
+        acc["oracle_diffusion_err"].append(float(np.max(np.abs(sol.diffusions - df) / np.abs(df))))
+    out.update({k: np.array(v) for k, v in acc.items()})
+    return out
 
 
 if __name__ == "__main__":
@@ -289,3 +340,14 @@ if __name__ == "__main__":
                 oracle_cov_err_final=cov_err(solp.covs(smoothed=False)[-1:], cfp[-1:]))
     np.savez_compressed(os.path.join(HERE, "exact_pleiades_ld.npz"), **outp)
     print("exact_pleiades_ld: oracle vs extended precision, filter blocks", outp["oracle_block_err_filt"], "final cov", outp["oracle_cov_err_final"])
+
+    # filter + smoother at the sizes of the GPU parity tests (tests/test_gpu_parity.py test_pleiades_ensemble_parity: 12 steps of
+    # config 4's dt = 2^-10), and order 5 once more with dt = 2^-6: at 2^-10 the residuals of the first steps of an order-5 solve are
+    # h^5-small, i.e. rounding noise in float64 (the oracle's own diffusions are 40 % off there) -- the larger step is where
+    # an order-5 covariance can be checked sharply
+    for q_, kind_, dt_, tag in ((2, "EK1", 2.0**-10, ""), (3, "EK0", 2.0**-10, ""), (5, "EK1", 2.0**-10, ""), (5, "EK1", 2.0**-6, "_dt6")):
+        fxp = pleiades_fixture(q_, kind_, 12, dt_)
+        name = f"exact_pleiades_{kind_.lower()}q{q_}{tag}_smooth_ld"
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **fxp)
+        print(name, ": oracle vs extended precision, filter blocks", fxp["oracle_block_err_filt"].max(axis=0), "cov", fxp["oracle_cov_err_filt"],
+              "| smoother blocks", fxp["oracle_block_err_smooth"].max(axis=0), "cov", fxp["oracle_cov_err_smooth"], "| diffusions", fxp["oracle_diffusion_err"])

@@ -58,6 +58,14 @@ def test_config2_lorenz_4096_filter_and_smoother(pkg):
         # sigma^2 = z' W^-1 z / d is a squared RESIDUAL: it inherits the noise of the highest derivative twice over
         np.testing.assert_allclose(ctx.get(2)[1:, gi], fx["diffusions"][k], rtol=2e-3)
         np.testing.assert_allclose(ctx.get(4)[gi], fx["loglik"][k], rtol=1e-6)
+    # trajectory 0 IS the trajectory of the 50-digit evaluation (tests/golden/exact_lorenz_mp.npz, all 1 025 records, filter and
+    # smoother): there the bar is not a flat number but the float64 oracle's own distance from the exact result, block by block
+    ex = np.load(os.path.join(GOLD, "exact_lorenz_mp.npz"))
+    np.testing.assert_array_equal(ctx.get(13)[:, 0], ex["u0"])
+    P.check_against_exact(mean[:, :, 0], pkg.unpack_tril(cov[:, :, 0], 12), ex["mean_filt"], ex["cov_filt"], ex["oracle_block_err_filt"],
+                          ex["oracle_cov_err_filt"], 3, "config 2 filter, trajectory 0 against the 50-digit evaluation")
+    P.check_against_exact(smean[:, :, 0], pkg.unpack_tril(scov[:, :, 0], 12), ex["mean_smooth"], ex["cov_smooth"], ex["oracle_block_err_smooth"],
+                          ex["oracle_cov_err_smooth"], 3, "config 2 smoother, trajectory 0 against the 50-digit evaluation")
     # final-only save mode = the last every-step record, bit for bit
     ctx2 = pkg.Context("lorenz63", 3, 1, N, save_everystep=False)
     ctx2.set_problem_perturbed(LORENZ_U0, LORENZ_P, 0.0, 1e-2)
@@ -106,6 +114,11 @@ def test_config4_pleiades_8192_final_state(pkg):
     assert np.isfinite(mean).all() and np.isfinite(cov).all()
     diag = np.array([k * (k + 1) // 2 + k for k in range(168)])
     assert (cov[diag] >= 0).all()
+    # positive semi-definite after 256 Joseph-form steps on the matrix cores (T - E K' is not PSD by construction):
+    # the fixture's trajectories and a spread of others, eigenvalues on the scale of the largest one
+    for gi in sorted(set(int(g) for g in fx["idx"]) | set(range(0, N, 547))):
+        w = np.linalg.eigvalsh(pkg.unpack_tril(cov[:, gi][None], 168)[0])
+        assert w.min() >= -1e-9 * np.abs(w).max(), (gi, w.min(), w.max())
     for k, gi in enumerate(fx["idx"]):
         np.testing.assert_allclose(ctx.get(13)[:, gi], fx["u0s"][k], rtol=0, atol=0)  # same ensemble as the fixture's
         np.testing.assert_allclose(mean[:28, gi], fx["u_final"][k], rtol=1e-10)

@@ -374,27 +374,42 @@ def test_pleiades_config4_golden(pkg):
     np.testing.assert_array_equal(sol2.x_filt_cov()[:, 0], sol.x_filt_cov()[:, -1])
 
 
-@pytest.mark.parametrize("q,kind", [(2, "EK1"), (3, "EK0"), (5, "EK1")])
-def test_pleiades_ensemble_parity(pkg, q, kind):
-    """Perturbed positions (1e-3, first 14 components) as in SURVEY 8(d) config 4, filter + smoother."""
+PLEIADES_EXACT = [(2, "EK1", ""), (3, "EK0", ""), (5, "EK1", ""), (5, "EK1", "_dt6")]
+
+
+@pytest.mark.parametrize("kernels", ["mfma+split", "mfma+persistent", "tiles+split"])
+@pytest.mark.parametrize("q,kind,tag", PLEIADES_EXACT, ids=[f"{k}{q}{t}" for q, k, t in PLEIADES_EXACT])
+def test_pleiades_ensemble_parity(pkg, q, kind, tag, kernels, monkeypatch):
+    """The workgroup-per-trajectory kernels (D = 84, 112, 168) against EXTENDED-PRECISION evaluations of the reference
+    algorithm (tests/golden/exact_pleiades_*_smooth_ld.npz, generator make_exact.py): perturbed positions (1e-3, first 14
+    components) as in SURVEY 8(d) config 4, 12 steps, filter + smoother, trajectories 0 and 4 of the ensemble.  Every
+    derivative block of the filtered and smoothed means, and the covariance of the last filter record and of smoothed
+    record 1, must be as close to the exact result as the float64 oracle is (factor 16) -- for the matrix-core filter
+    (Joseph form) and the register-tile filter (square-root form), the split smoother (a kernel per phase, sweeps on chip)
+    and the persistent one.  BASELINE order 5 twice: at config 4's dt = 2^-10, where the first residuals are h^5-small and the
+    reference arithmetic itself is rounding noise in the top blocks (the yardstick says so), and at dt = 2^-6, where the
+    same kernels are pinned to 1e-6 in the covariance.  No tolerance here is calibrated on a float64 run."""
+    fx = np.load(os.path.join(GOLD, f"exact_pleiades_{kind.lower()}q{q}{tag}_smooth_ld.npz"))
+    filt, smoother = kernels.split("+")
+    monkeypatch.setenv("ODEF_PLEIADES_FILTER", "tiles" if filt == "tiles" else "")
+    monkeypatch.setenv("ODEF_SMOOTH_SPLIT", "1" if smoother == "split" else "0")
     vf = orc.vector_field("pleiades")
-    N, ns, dt = 5, 12, 2.0**-10
+    N, ns, dt = 5, int(fx["nsteps"]), float(fx["dt"])
     ens = pkg.EnsembleProblem(pkg.ODEProblem("pleiades", vf.u0, (0.0, ns * dt), ()), perturb_scale=1e-3, n_perturbed=14)
     sol = pkg.solve(ens, _alg(pkg, kind, q), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
     u0s = orc.ensemble_u0(vf.u0, N, 1e-3, n_perturbed=14)
     np.testing.assert_array_equal(sol.ctx.get(13).T, u0s)
     assert sol.retcode == ["Success"] * N
-    mf, ms = sol.x_filt_mean(), sol.x_smooth_mean()
-    alg_o = orc.Alg(kind, q, "dynamic", True)
-    for i in (0, 4):
-        ref = orc.solve(vf, alg_o, u0=u0s[i], tspan=(0.0, ns * dt), dt=dt)
-        np.testing.assert_allclose(mf[i][:, :28], ref.means(smoothed=False)[:, :28], rtol=1e-11, atol=1e-13)
-        np.testing.assert_allclose(ms[i][:, :28], ref.means(smoothed=True)[:, :28], rtol=1e-11, atol=1e-13)
-        if q < 5:  # at order 5 the first steps' residuals are rounding noise in both implementations
-            for smoothed, m, c in ((False, mf, sol.x_filt_cov()), (True, ms, sol.x_smooth_cov())):
-                base, nm, nc = P.oracle_noise(vf, alg_o, u0s[i], dict(tspan=(0.0, ns * dt), dt=dt), smoothed)
-                P.check_against_oracle(m[i], c[i], base.means(smoothed=smoothed), base.covs(smoothed=smoothed), 28, nm, nc,
-                                       f"pleiades {kind}({q}) traj {i} smoothed={smoothed}")
+    mf, ms, cf, cs = sol.x_filt_mean(), sol.x_smooth_mean(), sol.x_filt_cov(), sol.x_smooth_cov()
+    for k, i in enumerate(fx["trajs"]):
+        np.testing.assert_array_equal(u0s[i], fx["u0s"][k])
+        np.testing.assert_allclose(mf[i][:, :28], fx["mean_filt"][k][:, :28], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(ms[i][:, :28], fx["mean_smooth"][k][:, :28], rtol=1e-11, atol=1e-13)
+        P.check_against_exact_fixture(fx, k, mf[i], cf[i], ms[i], cs[i], 28, f"pleiades {kind}({q}){tag} {kernels} traj {i}")
+        # positive semi-definite, on the scale of the largest eigenvalue
+        for c in (cf[i][-1], cs[i][1]):
+            w = np.linalg.eigvalsh(c)
+            assert w.min() >= -1e-9 * np.abs(w).max()
 
 
 @pytest.mark.parametrize("q", [1, 3, 5])
@@ -418,7 +433,11 @@ def test_pleiades_mfma_kernel_against_tiles_kernel_nonuniform_grid(pkg, q, monke
     (m1, c1, d1, l1), (m0, c0, d0, l0) = out["mfma"], out["tiles"]
     assert np.isfinite(m1).all() and np.isfinite(c1).all()
     np.testing.assert_allclose(m1[:, :28], m0[:, :28], rtol=1e-11, atol=1e-13)
-    np.testing.assert_allclose(d1[2:], d0[2:], rtol=1e-6 if q < 5 else 0.2)  # order 5: the first residuals are rounding noise (see test_dense_output_pleiades)
+    # Order 5 at these step sizes: the residuals of the first steps are h^5-small, i.e. rounding noise in ANY float64 arithmetic
+    # (tests/golden/exact_pleiades_ek1q5_smooth_ld.npz: the oracle's own diffusions are 40 % - 300x off the extended-precision
+    # ones), so two correct kernels need not agree in them; what order 5 guarantees is asserted against the extended-precision
+    # fixtures in test_pleiades_ensemble_parity (both filters, dt = 2^-10 and 2^-6).
+    np.testing.assert_allclose(d1[2:], d0[2:], rtol=1e-6 if q < 5 else 0.2)
     if q < 5:
         np.testing.assert_allclose(l1, l0, rtol=1e-6)
 
@@ -704,9 +723,13 @@ def test_dense_output_adaptive_common_times(pkg):
 @pytest.mark.parametrize("q", [2, 5])
 def test_dense_output_pleiades(pkg, q, smooth):
     """sol(t) on the workgroup-per-trajectory path (state dimension 84 / 168, csrc/dense_mfma.h) against the oracle's
-    dense output (src/solution.jl:165-210): inside the grid, at a stored time, beyond the last time, before t0."""
+    dense output (src/solution.jl:165-210): inside the grid, at a stored time, beyond the last time, before t0.
+    Order 5 runs with dt = 2^-6: at config 4's 2^-10 the first residuals of an order-5 solve are h^5-small and every
+    covariance (proportional to the diffusion estimates) is rounding noise in the reference arithmetic itself
+    (tests/golden/make_exact.py); at 2^-6 the oracle is within 3e-7 of the extended-precision covariance, so the
+    interpolated covariances ARE compared at order 5 too."""
     vf = orc.vector_field("pleiades")
-    N, ns, dt = 3, 12, 2.0**-10
+    N, ns, dt = 3, 12, (2.0**-10 if q < 5 else 2.0**-6)
     ens = pkg.EnsembleProblem(pkg.ODEProblem("pleiades", vf.u0, (0.0, ns * dt), ()), perturb_scale=1e-3, n_perturbed=14)
     sol = pkg.solve(ens, pkg.EK1(order=q, smooth=smooth), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
     grid = sol.t
@@ -720,14 +743,10 @@ def test_dense_output_pleiades(pkg, q, smooth):
             r = orc.dense_output(ref, consts, float(t), smoothed=smooth)
             np.testing.assert_allclose(qm[i, j, :28], r.mu[:28], rtol=1e-10, atol=1e-13, err_msg=f"traj {i} t={t}")
             c = r.cov()
-            # compared on the scale of its largest entry -- at order 2.  At order 5 the residuals of these first steps, and
-            # with them the diffusion estimates every covariance is proportional to, are rounding noise in both implementations
-            # (entries of 1e-30, 10 % apart; the same reason test_pleiades_ensemble_parity checks no covariance at order 5):
-            # there the covariance is only required to be finite and symmetric-positive on its diagonal.
-            if q < 5:
-                assert np.abs(qc[i, j] - c).max() <= 1e-6 * np.abs(c).max() + 1e-300, (i, j)
-            else:
-                assert np.isfinite(qc[i, j]).all() and (np.diag(qc[i, j]) >= 0).all(), (i, j)
+            # on the scale of its largest entry: 1e-6 at order 2; 1e-4 at order 5 (oracle - extended precision there: 3e-7 in the
+            # filter covariance, 3e-9 in the smoothed one; the Joseph-form kernels sit within 16x of that, test_pleiades_ensemble_parity)
+            assert np.abs(qc[i, j] - c).max() <= (1e-6 if q < 5 else 1e-4) * np.abs(c).max() + 1e-300, (i, j)
+            assert (np.diag(qc[i, j]) >= 0).all()
     np.testing.assert_array_equal(qm[:, 2], (sol.x_smooth_mean() if smooth else sol.x_filt_mean())[:, 7])
     qm2, _ = sol(np.array([-0.1]))
     assert np.all(np.isnan(qm2))
