@@ -236,6 +236,16 @@ int odef_kernel_name(odef_ctx* ctx, int which, char* buf, size_t n);
 typedef struct odef_group odef_group;
 /* block [first, first + count) of shard `shard` out of n_shards: the first n_traj % n_shards shards are one longer */
 int odef_shard_range(int64_t n_traj, int32_t n_shards, int32_t shard, int64_t* first, int64_t* count);
+/* Layout of the gathered block (host arithmetic, no device needed): every device ends odef_allgather with
+ * [n_devices][state_dim][cnt_max] doubles -- shard k's final means in block k, its `count[k]` columns first, the columns
+ * up to cnt_max = the longest shard's count zero-padded (RCCL's all-gather wants equal blocks).  first / count: arrays of
+ * n_devices entries (either may be NULL); block_doubles = state_dim * cnt_max.  What a caller that consumes the block on
+ * the device (odef_group_get_gathered's dev_ptr) needs to address it. */
+int odef_group_layout(int64_t n_traj, int32_t n_devices, int32_t state_dim, int64_t* first, int64_t* count, int64_t* cnt_max,
+                      int64_t* block_doubles);
+/* ... and the same block with the padding dropped: gathered [n_devices][state_dim][cnt_max] (host memory) ->
+ * dst [state_dim][n_traj], trajectory index fastest as everywhere.  odef_group_get_gathered's host path is this function. */
+int odef_unpad_gathered(const double* gathered, int32_t n_devices, int32_t state_dim, int64_t n_traj, double* dst);
 /* cfg->n_traj is the size of the WHOLE ensemble; cfg->device is ignored; device_ids == NULL: devices 0..n_devices-1 */
 int odef_group_create(odef_group** out, const odef_config* cfg, int32_t n_devices, const int32_t* device_ids);
 void odef_group_destroy(odef_group* g);

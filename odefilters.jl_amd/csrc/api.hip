@@ -1067,6 +1067,36 @@ extern "C" {
 
 const char* odef_group_last_error(const odef_group* g) { return g ? g->err.c_str() : g_create_error.c_str(); }
 
+int odef_group_layout(int64_t n_traj, int32_t n_devices, int32_t state_dim, int64_t* first, int64_t* count, int64_t* cnt_max,
+                      int64_t* block_doubles) {
+  if (n_devices < 1 || n_traj < n_devices || state_dim < 1) return -1;
+  int64_t longest = 0;
+  for (int32_t k = 0; k < n_devices; ++k) {
+    int64_t f = 0, c = 0;
+    if (odef_shard_range(n_traj, n_devices, k, &f, &c) != 0) return -1;
+    if (first) first[k] = f;
+    if (count) count[k] = c;
+    longest = c > longest ? c : longest;
+  }
+  if (cnt_max) *cnt_max = longest;
+  if (block_doubles) *block_doubles = (int64_t)state_dim * longest;
+  return 0;
+}
+
+int odef_unpad_gathered(const double* gathered, int32_t n_devices, int32_t state_dim, int64_t n_traj, double* dst) {
+  if (!gathered || !dst) return -1;
+  int64_t cnt_max = 0, blk = 0;
+  if (odef_group_layout(n_traj, n_devices, state_dim, nullptr, nullptr, &cnt_max, &blk) != 0) return -1;
+  for (int32_t k = 0; k < n_devices; ++k) {  // drop the padding columns of the shorter shards
+    int64_t f = 0, c = 0;
+    odef_shard_range(n_traj, n_devices, k, &f, &c);
+    for (int32_t r = 0; r < state_dim; ++r)
+      std::memcpy(dst + (size_t)r * (size_t)n_traj + (size_t)f, gathered + (size_t)k * (size_t)blk + (size_t)r * (size_t)cnt_max,
+                  (size_t)c * sizeof(double));
+  }
+  return 0;
+}
+
 int odef_group_create(odef_group** out, const odef_config* cfg, int32_t n_devices, const int32_t* device_ids) {
   if (!out || !cfg) return gfail(nullptr, "odef_group_create: null argument");
   *out = nullptr;
@@ -1241,10 +1271,7 @@ int odef_group_get_gathered(odef_group* g, int32_t shard, double* host_dst /* [D
     std::vector<double> tmp(blk * G);
     if (hipMemcpy(tmp.data(), g->recv[shard], tmp.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
       return gfail(g, "odef_group_get_gathered: copy from device %d failed", c->device);
-    for (int k = 0; k < G; ++k)  // drop the padding columns of the shorter shards
-      for (int r = 0; r < g->D; ++r)
-        std::memcpy(host_dst + (size_t)r * g->n_total + g->first[k], tmp.data() + (size_t)k * blk + (size_t)r * g->cnt_max,
-                    (size_t)g->count[k] * sizeof(double));
+    if (odef_unpad_gathered(tmp.data(), G, g->D, g->n_total, host_dst) != 0) return gfail(g, "odef_group_get_gathered: inconsistent layout");
   }
   return 0;
 }

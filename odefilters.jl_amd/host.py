@@ -84,6 +84,8 @@ SYMBOLS = {
     "odef_smooth_step": (C.c_int, [C.c_int, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     # ensemble sharded over the GPUs of one node by one process
     "odef_shard_range": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "odef_group_layout": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "odef_unpad_gathered": (C.c_int, [_dp, C.c_int32, C.c_int32, C.c_int64, _dp]),
     "odef_group_create": (C.c_int, [C.POINTER(_vp), C.POINTER(OdefConfig), C.c_int32, C.POINTER(C.c_int32)]),
     "odef_group_destroy": (None, [_vp]),
     "odef_group_last_error": (C.c_char_p, [_vp]),
