@@ -153,8 +153,10 @@ const char* odef_last_error(const odef_ctx* ctx); /* ctx may be NULL: last error
  *     };
  *
  * A hipcc child process ($ODEFILTER_HIP_HIPCC, else hipcc on PATH, else /opt/rocm/bin/hipcc) compiles the library's
- * own lane kernels around it for gfx950 (include_dir = directory holding the csrc headers; NULL: $ODEFILTER_HIP_INCLUDE
- * or the build-time location).  Returns 0 and a new rhs id (>= 100) for
+ * own kernels around it for gfx950 -- one lane per trajectory, and for d(q+1) <= 16 also the 16-lanes-per-trajectory kernels
+ * that small and sharded ensembles use, chosen by ensemble size exactly as for the compiled-in fields -- (include_dir =
+ * directory holding the csrc headers; NULL: $ODEFILTER_HIP_INCLUDE, else ../csrc next to the loaded library, else the
+ * build-time location).  Returns 0 and a new rhs id (>= 100) for
  * odef_config.rhs_id; on a compile error returns -1 and odef_last_error(NULL) holds the compiler log.
  * Filter and smoother: d <= 10 and d(q+1) <= 20; dense output and sampling: d(q+1) <= 12.  Whatever the compiler
  * rejects comes back as an error with its log. */

@@ -612,13 +612,17 @@ int odef_solve_fixed(odef_ctx* c, const double* tgrid, int64_t n_t) {
     if ((size_t)c->TRI * (size_t)c->cfg.n_traj * sizeof(double) >= (1ull << 31))
       return fail(c, "odef_solve_fixed: n_traj * D(D+1)/2 * 8 bytes must stay below 2 GiB per save slot; shard the ensemble");
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    if (c->jit)
+    if (c->jit && c->jit->rows16 && P.N < filter_rows_max_n()) {  // small ensemble: 16 lanes per trajectory, as for the compiled-in fields
+      note_kernel(P.everystep ? "odef_jit_rows_fixed_every" : "odef_jit_rows_fixed_final");
+      rc = jit_launch(P.everystep ? c->jit->rows_fixed_every : c->jit->rows_fixed_final, rows_grid(P.N), 1, &P, c->stream, 256);
+    } else if (c->jit) {
+      note_kernel(P.everystep ? "odef_jit_fixed_every" : "odef_jit_fixed_final");
       rc = jit_launch(P.everystep ? c->jit->fixed_every : c->jit->fixed_final, (unsigned)((P.N + 63) / 64), 1, &P, c->stream);
-    else
+    } else
       rc = launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 0, P, c->stream);
   }
   if (rc) return fail(c, "odef_solve_fixed: no kernel for rhs %d order %d", c->cfg.rhs_id, c->q);
-  std::snprintf(c->kname[0], sizeof c->kname[0], "%s", c->jit ? (P.everystep ? "odef_jit_fixed_every" : "odef_jit_fixed_final") : last_kernel());
+  std::snprintf(c->kname[0], sizeof c->kname[0], "%s", last_kernel());
   return finish_filter(c, 1);
 }
 
@@ -652,11 +656,19 @@ int odef_solve_adaptive(odef_ctx* c, double t1, double abstol, double reltol, do
   }
   HIPCHK(c, hipMemsetAsync(c->f[ODEF_F_T].ptr, 0, c->f[ODEF_F_T].valid, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  const int rc = c->jit         ? jit_launch(c->jit->adaptive, (unsigned)((P.N + 63) / 64), 1, &P, c->stream)
-                 : c->team_path ? launch_filter_pleiades_tiles(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 1)
-                                : launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 1, P, c->stream);
+  int rc;
+  if (c->jit && c->jit->rows16 && P.N < filter_rows_max_n()) {
+    note_kernel("odef_jit_rows_adaptive");
+    rc = jit_launch(c->jit->rows_adaptive, rows_grid(P.N), 1, &P, c->stream, 256);
+  } else if (c->jit) {
+    note_kernel("odef_jit_adaptive");
+    rc = jit_launch(c->jit->adaptive, (unsigned)((P.N + 63) / 64), 1, &P, c->stream);
+  } else {
+    rc = c->team_path ? launch_filter_pleiades_tiles(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 1)
+                      : launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 1, P, c->stream);
+  }
   if (rc) return fail(c, "odef_solve_adaptive: no kernel for rhs %d order %d", c->cfg.rhs_id, c->q);
-  std::snprintf(c->kname[0], sizeof c->kname[0], "%s", c->jit ? "odef_jit_adaptive" : last_kernel());
+  std::snprintf(c->kname[0], sizeof c->kname[0], "%s", last_kernel());
   return finish_filter(c, 1);
 }
 
@@ -692,10 +704,15 @@ int odef_smooth(odef_ctx* c) {
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   int rc;
   if (c->jit)
-    if (c->jit->posterior)
+    if (c->jit->rows16 && S.N < smooth_rows_max_n()) {  // small ensemble: the DPP row-team smoother
+      note_kernel(S.adaptive ? "odef_jit_bcast_adapt" : "odef_jit_bcast_fixed");
+      rc = jit_launch(S.adaptive ? c->jit->bcast_adapt : c->jit->bcast_fixed, rows_grid(S.N), 1, &S, c->stream, 256);
+    } else if (c->jit->posterior) {
+      note_kernel(S.adaptive ? "odef_jit_smooth_adapt" : "odef_jit_smooth_fixed");
       rc = jit_launch(S.adaptive ? c->jit->smooth_adapt : c->jit->smooth_fixed, (unsigned)((S.N + 63) / 64), 1, &S, c->stream);
-    else if (c->jit->smooth_rows) {
+    } else if (c->jit->smooth_rows) {
       const long tpb = 64 / c->jit->rows_team;
+      note_kernel("odef_jit_smooth_rows");
       rc = jit_launch(c->jit->smooth_rows, (unsigned)((S.N + tpb - 1) / tpb), 1, &S, c->stream);
     } else
       rc = -3;
@@ -719,8 +736,7 @@ int odef_smooth(odef_ctx* c) {
   } else
     rc = launch_smooth(c->d, c->q, S, c->stream);
   if (rc) return fail(c, "odef_smooth: no kernel for d %d order %d", c->d, c->q);
-  std::snprintf(c->kname[1], sizeof c->kname[1], "%s",
-                c->jit ? (c->jit->posterior ? (S.adaptive ? "odef_jit_smooth_adapt" : "odef_jit_smooth_fixed") : "odef_jit_smooth_rows") : last_kernel());
+  std::snprintf(c->kname[1], sizeof c->kname[1], "%s", last_kernel());
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   HIPCHK(c, hipGetLastError());
   c->nl[1] = 1;

@@ -16,6 +16,7 @@
 #include "filter_mfma.h"
 #include "rows_filter.h"
 #include "rows_smooth.h"
+#include "rows_kernels.h"
 #include "smooth_mfma.h"
 #include "dense_rows.h"
 #include "sample_rows.h"
@@ -40,56 +41,6 @@ __global__ __launch_bounds__(kWave) void ek_filter_fixed_kernel(const FilterPara
     for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
   }
   if (i0 + threadIdx.x < P.N) filter_fixed_lane<RHS, q, EK1, EVERY, LAG>(P, i0, threadIdx.x);
-}
-// Small / sharded ensembles: 16 lanes per trajectory (rows_filter.h), 4 trajectories per wavefront.
-// Workgroups go round-robin over the 8 XCDs; the block -> trajectory map gives each XCD one contiguous range of
-// trajectories, so that the 32-byte runs neighbouring wavefronts write into one cache line meet in the same L2.
-constexpr int kRowsMaxD = tv::kTeam;
-// Ensemble size below which the filter uses the row-team kernels.  Cost model from tools/dpp_bench.hip: a wavefront
-// alone on its SIMD issues one instruction per ~3 ns whatever it is, so the lane kernel needs ~5 us per step at any
-// N <= 65 536 and the row-team kernel (I instructions per wave-step, N / 4 waves) I x 3 ns x max(1, N / 4096);
-// measured crossover: profiles/r02_rows_vs_lane.jsonl.  ODEF_FILTER_ROWS_MAX_N overrides it (read at every launch,
-// so tests can exercise both kernels).
-constexpr long kFilterRowsMaxN = 12288;
-inline long filter_rows_max_n() {
-  const char* e = getenv("ODEF_FILTER_ROWS_MAX_N");
-  return e ? atol(e) : kFilterRowsMaxN;
-}
-// Workgroup = 4 wavefronts = 16 teams = 16 consecutive trajectories: one 128-byte line per record element (rows_store.h).
-constexpr int kRowsBlock = kRowsWgTeams * tv::kTeam;  // 256 threads
-template <int d, int NB, int STAGE>
-struct RowsLds {  // doubles: 16 teams' exchange rows + the staging image of the record stores
-  static constexpr int team = tv::lds_rows(d, NB) * tv::lds_ld(d * NB);
-  static constexpr int size = kRowsWgTeams * team + STAGE;
-};
-__device__ inline RowsTeam rows_team(long N, double* lds, int team_doubles) {
-  const long per = (long)(gridDim.x / 8u);  // the grid is a multiple of 8 workgroups
-  const long g = (long)(blockIdx.x % 8u) * per + (long)(blockIdx.x / 8u);
-  RowsTeam tm;
-  tm.tcol = (int)(threadIdx.x / tv::kTeam);
-  tm.i16 = g * kRowsWgTeams;
-  const long i = tm.i16 + tm.tcol;
-  tm.valid = i < N;
-  tm.i = tm.valid ? i : N - 1;  // padding teams of the last workgroup compute a duplicate and store nothing
-  tm.lds_team = lds + tm.tcol * team_doubles;
-  tm.stage = lds + kRowsWgTeams * team_doubles;
-  return tm;
-}
-inline unsigned rows_grid(long N) { return (unsigned)(((N + kRowsWgTeams - 1) / kRowsWgTeams + 7) / 8 * 8); }
-template <class RHS, int q, bool EK1, bool EVERY>
-__global__ __launch_bounds__(kRowsBlock) void ek_filter_rows_kernel(const FilterParams P) {
-  using L = RowsLds<RHS::d, q + 1, EVERY ? RowsSink<RHS::d*(q + 1), true, false>::kStageDoubles : 0>;
-  __shared__ __attribute__((aligned(16))) double lds[L::size];
-  const RowsTeam tm = rows_team(P.N, lds, L::team);
-  if (tm.i16 < P.N) rows_filter_fixed<RHS, q, EK1, EVERY>(P, tm);  // workgroup-uniform
-}
-template <class RHS, int q, bool EK1>
-__global__ __launch_bounds__(kRowsBlock) void ek_filter_rows_adaptive_kernel(const FilterParams P) {
-  using S = RowsStep<RHS, q, EK1>;
-  constexpr int kStage = RowsSink<S::D, true, true>::kStageDoubles;
-  __shared__ __attribute__((aligned(16))) double lds[kRowsWgTeams * S::kLdsDoublesAdaptive + kStage];
-  const RowsTeam tm = rows_team(P.N, lds, S::kLdsDoublesAdaptive);
-  if (tm.i16 < P.N) rows_filter_adaptive<RHS, q, EK1>(P, tm);
 }
 template <class RHS, int q, bool EK1>
 __global__ __launch_bounds__(kWave) void ek_filter_adaptive_kernel(const FilterParams P) {
@@ -127,36 +78,6 @@ constexpr long kSmoothLaneMinN = 6144;
 inline long smooth_lane_min_n() {
   const char* e = getenv("ODEF_SMOOTH_LANE_MIN_N");
   return e ? atol(e) : kSmoothLaneMinN;
-}
-// Smoother on DPP broadcasts (rows_smooth.h), 16 lanes per trajectory, D <= 16: small and sharded ensembles.
-// ODEF_SMOOTH_ROWS_MAX_N overrides the crossover (read at every launch); which of the three smoothers runs for D <= 12:
-//   N < kSmoothRowsMaxN: this kernel;  otherwise the lane kernel (N >= kSmoothLaneMinN) or the LDS row teams.
-#ifndef ODEF_ROWS_SMOOTH_WAVES
-#define ODEF_ROWS_SMOOTH_WAVES 2  // waves per SIMD the smoother is compiled for (<= 256 registers)
-#endif
-constexpr long kSmoothRowsMaxN = 49152;
-inline long smooth_rows_max_n() {
-  const char* e = getenv("ODEF_SMOOTH_ROWS_MAX_N");
-  return e ? atol(e) : kSmoothRowsMaxN;
-}
-template <int d, int q, bool ADAPT>
-__global__ __launch_bounds__(kRowsBlock) void rts_smooth_bcast_kernel(const SmoothParams P) {
-  using SM = RowsSmoother<d, q, ADAPT>;
-  constexpr int kStage = RowsSink<d*(q + 1), false, false>::kStageDoubles;
-  __shared__ __attribute__((aligned(16))) double lds[kRowsWgTeams * SM::kLdsDoubles + kStage];
-  __shared__ int wg_n_hi;
-  const RowsTeam tm = rows_team(P.N, lds, SM::kLdsDoubles);
-  if (tm.i16 >= P.N) return;  // workgroup-uniform
-  long n_hi = P.n_save;
-  if constexpr (ADAPT) {  // largest record count among the workgroup's trajectories
-    if (threadIdx.x == 0) wg_n_hi = 0;
-    __syncthreads();
-    if (tm.valid && threadIdx.x % tv::kTeam == 0) atomicMax(&wg_n_hi, P.nsaved[tm.i]);
-    __syncthreads();
-    n_hi = wg_n_hi;
-  }
-  RowsSmoother<d, q, ADAPT> sm;
-  sm.run(P, tm, n_hi);
 }
 // Two kernels (fixed grid / adaptive records) so that each gets its own register allocation.
 template <int d, int q, bool ADAPT>

@@ -16,6 +16,10 @@ struct JitModule {
   hipFunction_t dense_rows = nullptr;   // ... and dense output on the same teams (one team per (trajectory, query time))
   hipFunction_t sample_rows = nullptr;  // ... and posterior sampling (one team per (trajectory, sample))
   int rows_team = 16;                   // lanes per trajectory of that kernel
+  // state dimension <= 16: the 16-lanes-per-trajectory kernels of small and sharded ensembles (rows_kernels.h), workgroups of 256
+  hipFunction_t rows_fixed_every = nullptr, rows_fixed_final = nullptr, rows_adaptive = nullptr;
+  hipFunction_t bcast_fixed = nullptr, bcast_adapt = nullptr;
+  bool rows16 = false;
   bool posterior = false;  // lane smoother / dense output / sampler available (state dimension <= 12)
 };
 
@@ -24,7 +28,8 @@ int jit_register(const char* name, const char* source, int d, int np, const char
 bool jit_lookup(int rhs_id, int* d, int* np);
 // compiles (once per (rhs, order, alg, device)) and loads the kernels on the CURRENT device
 JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& err);
-// one wavefront per block; params: pointer to the kernel's single by-value parameter struct
-int jit_launch(hipFunction_t f, unsigned gx, unsigned gy, const void* params, hipStream_t s);
+// `block` threads per workgroup (64: the lane and LDS row-team kernels; 256: rows_kernels.h); params: pointer to the kernel's
+// single by-value parameter struct
+int jit_launch(hipFunction_t f, unsigned gx, unsigned gy, const void* params, hipStream_t s, unsigned block = 64);
 
 }  // namespace odef

@@ -71,6 +71,8 @@ std::string translation_unit(const JitRhs& r, int q, int ek1, bool with_posterio
   if (with_posterior_kernels) s += "#include \"smooth_lane.h\"\n#include \"dense_lane.h\"\n#include \"sample_lane.h\"\n";
   const bool rows_smoother = !with_posterior_kernels && D <= 32;  // 12 < D <= 32: the row-per-lane team smoother
   if (rows_smoother) s += "#include \"smooth_rows.h\"\n#include \"dense_rows.h\"\n#include \"sample_rows.h\"\n";
+  const bool rows16 = D <= 16;  // the 16-lanes-per-trajectory filter and smoother of small ensembles (rows_kernels.h)
+  if (rows16) s += "#include \"rows_kernels.h\"\n";
   s += "namespace odef {\n";
   s += r.source;
   s += "\nusing RhsJit = " + r.name + ";\n";
@@ -138,6 +140,18 @@ std::string translation_unit(const JitRhs& r, int q, int ek1, bool with_posterio
          "  const long it = (long)blockIdx.x * TPB + team;\n"
          "  RowState<" + DD + " * (" + Q + " + 1)> st;\n"
          "  if (it < P.N * P.n_samples) sample_rows_lane<" + DD + ", " + Q + ", TEAM>(P, it % P.N, it / P.N, tid, lds + team * W::size, &st);\n}\n";
+  }
+  if (rows16) {
+    s += "extern \"C\" __global__ __launch_bounds__(256) void odef_jit_rows_fixed_every(const FilterParams P) {\n"
+         "  rows_filter_fixed_entry<RhsJit, " + Q + ", " + EK + ", true>(P);\n}\n";
+    s += "extern \"C\" __global__ __launch_bounds__(256) void odef_jit_rows_fixed_final(const FilterParams P) {\n"
+         "  rows_filter_fixed_entry<RhsJit, " + Q + ", " + EK + ", false>(P);\n}\n";
+    s += "extern \"C\" __global__ __launch_bounds__(256) void odef_jit_rows_adaptive(const FilterParams P) {\n"
+         "  rows_filter_adaptive_entry<RhsJit, " + Q + ", " + EK + ">(P);\n}\n";
+    s += "extern \"C\" __global__ __launch_bounds__(256) void odef_jit_bcast_fixed(const SmoothParams P) {\n"
+         "  rows_smooth_entry<" + DD + ", " + Q + ", false>(P);\n}\n";
+    s += "extern \"C\" __global__ __launch_bounds__(256) void odef_jit_bcast_adapt(const SmoothParams P) {\n"
+         "  rows_smooth_entry<" + DD + ", " + Q + ", true>(P);\n}\n";
   }
   s += "}  // namespace odef\n";
   return s;
@@ -378,6 +392,7 @@ JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& e
   auto m = std::make_unique<JitModule>();
   m->posterior = r.d * (q + 1) <= 12;  // the lane smoother / dense output / sampler keep a packed matrix per lane in LDS
   m->rows_team = r.d * (q + 1) <= 16 ? 16 : 32;
+  m->rows16 = r.d * (q + 1) <= 16;
   std::vector<char> code;
   const int D = r.d * (q + 1);
   const int agpr_first_slot = m->posterior ? 2 * (128 - (D * (D + 1) / 2 + D)) : -1;  // MS of smooth_lane_v2 (smooth_lane.h)
@@ -394,7 +409,12 @@ JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& e
       {&m->sample, "odef_jit_sample", m->posterior},
       {&m->smooth_rows, "odef_jit_smooth_rows", !m->posterior && r.d * (q + 1) <= 32},
       {&m->dense_rows, "odef_jit_dense_rows", !m->posterior && r.d * (q + 1) <= 32},
-      {&m->sample_rows, "odef_jit_sample_rows", !m->posterior && r.d * (q + 1) <= 32}};
+      {&m->sample_rows, "odef_jit_sample_rows", !m->posterior && r.d * (q + 1) <= 32},
+      {&m->rows_fixed_every, "odef_jit_rows_fixed_every", m->rows16},
+      {&m->rows_fixed_final, "odef_jit_rows_fixed_final", m->rows16},
+      {&m->rows_adaptive, "odef_jit_rows_adaptive", m->rows16},
+      {&m->bcast_fixed, "odef_jit_bcast_fixed", m->rows16},
+      {&m->bcast_adapt, "odef_jit_bcast_adapt", m->rows16}};
   for (auto& e : fn) {
     if (!e.need) continue;
     if (hipModuleGetFunction(e.f, m->mod, e.name) != hipSuccess) {
@@ -414,9 +434,9 @@ JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& e
   return out;
 }
 
-int jit_launch(hipFunction_t f, unsigned gx, unsigned gy, const void* params, hipStream_t s) {
+int jit_launch(hipFunction_t f, unsigned gx, unsigned gy, const void* params, hipStream_t s, unsigned block) {
   void* args[] = {const_cast<void*>(params)};
-  return hipModuleLaunchKernel(f, gx, gy, 1, 64, 1, 1, 0, s, args, nullptr) == hipSuccess ? 0 : -4;
+  return hipModuleLaunchKernel(f, gx, gy, 1, block, 1, 1, 0, s, args, nullptr) == hipSuccess ? 0 : -4;
 }
 
 }  // namespace odef

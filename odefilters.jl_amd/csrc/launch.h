@@ -6,6 +6,7 @@
 #include "team.h"
 #include "dense_lane.h"
 #include "sample_lane.h"
+#include "rows_launch.h"
 
 namespace odef {
 // The launchers say which kernel they picked (printf-style; the name a profiler prints); api.hip hands it out through

@@ -1030,13 +1030,16 @@ def _l96_field():
     return orc.VectorField("l96", 100, 4, 1, f, jac, np.array([1.0, 2.0, 0.5, -1.0]), np.array([8.0]), (0.0, 0.25))
 
 
-def test_user_vector_field_equals_the_compiled_in_one(pkg, monkeypatch):
+@pytest.mark.parametrize("kernels", ["lane", "rows"])
+def test_user_vector_field_equals_the_compiled_in_one(pkg, kernels, monkeypatch):
     """The same Lorenz-63 text through odef_rhs_compile (hipcc child process) and through the compiled-in registry: identical
-    kernels source, so identical results -- fixed grid + smoother, adaptive, dense output, sampling.  (Run-time compiled
-    fields get the lane kernels; the compiled-in side is pinned to them too -- by default 70 trajectories would go to the
-    row-team kernels, which agree to rounding only.)"""
-    monkeypatch.setenv("ODEF_FILTER_ROWS_MAX_N", "0")
-    monkeypatch.setenv("ODEF_SMOOTH_ROWS_MAX_N", "0")
+    kernels source, so identical results -- fixed grid + smoother, adaptive, dense output, sampling.  Run-time compiled
+    fields get BOTH kernel families of the small state dimensions (round 3): one lane per trajectory, and -- below the same
+    ensemble sizes as the compiled-in fields -- 16 lanes per trajectory (rows_kernels.h); each is compared with the
+    compiled-in kernels of its own family, pinned by the launcher's environment switches."""
+    big = "1000000000"
+    monkeypatch.setenv("ODEF_FILTER_ROWS_MAX_N", "0" if kernels == "lane" else big)
+    monkeypatch.setenv("ODEF_SMOOTH_ROWS_MAX_N", "0" if kernels == "lane" else big)
     monkeypatch.setenv("ODEF_SMOOTH_LANE_MIN_N", "1")  # (70 trajectories would otherwise go to the LDS row-team smoother)
     pkg.compile_rhs("UserLorenz", USER_LORENZ, 3, 3)
     vf = orc.vector_field("lorenz63")
@@ -1049,6 +1052,10 @@ def test_user_vector_field_equals_the_compiled_in_one(pkg, monkeypatch):
             sols.append(pkg.solve(ens, pkg.EK1(order=3), pkg.EnsembleHIP(), trajectories=N, **kw))
         a, b = sols
         assert b.retcode == ["Success"] * N
+        want = {("lane", False): ("odef_jit_fixed_every", "odef_jit_smooth_fixed"), ("lane", True): ("odef_jit_adaptive", "odef_jit_smooth_adapt"),
+                ("rows", False): ("odef_jit_rows_fixed_every", "odef_jit_bcast_fixed"), ("rows", True): ("odef_jit_rows_adaptive", "odef_jit_bcast_adapt")}
+        assert (b.ctx.kernel_name(0), b.ctx.kernel_name(1)) == want[kernels, adaptive]
+        assert ("rows" in a.ctx.kernel_name(0)) == (kernels == "rows") and ("bcast" in a.ctx.kernel_name(1)) == (kernels == "rows")
         # same source, same compiler back end; tolerances only allow for a different contraction/scheduling choice
         # (higher-derivative components amplify one ulp, tests/_parity.py)
         np.testing.assert_allclose(b.x_filt_mean()[..., :3], a.x_filt_mean()[..., :3], rtol=1e-12, atol=0)
@@ -1117,6 +1124,58 @@ def test_user_vector_field_larger_state(pkg, d, q):
     s1 = sol.sample_states(3, 7)
     assert np.isfinite(s1).all()
     np.testing.assert_array_equal(sol.sample_states(3, 7), s1)
+
+
+def test_user_vector_field_on_the_row_team_kernels_at_config2_size(pkg):
+    """A user vector field with d = 5 at order 2 (D = 15: no compiled-in kernel has this shape) and 4 096 trajectories -- the
+    ensemble size of BASELINE config 2, where the lane kernels would occupy 64 of the chip's 1 024 SIMDs: the library must
+    pick the run-time compiled 16-lanes-per-trajectory filter and smoother (asked through odef_kernel_name, not assumed), and
+    their results must agree with the oracle and with the lane filter + LDS row-team smoother forced on the same ensemble."""
+    name, d, q = "UserL96d5cfg2", 5, 2
+    pkg.compile_rhs(name, _l96_source(name, d), d, 1)
+
+    def f(u, p, t):
+        return [(u[(i + 1) % d] - u[(i + d - 2) % d]) * u[(i + d - 1) % d] - u[i] + p[0] for i in range(d)]
+
+    def jac(u, p, t):
+        J = np.zeros((d, d))
+        for i in range(d):
+            ip, im2, im1 = (i + 1) % d, (i + d - 2) % d, (i + d - 1) % d
+            J[i, ip] += u[im1]
+            J[i, im2] -= u[im1]
+            J[i, im1] += u[ip] - u[im2]
+            J[i, i] -= 1.0
+        return J
+
+    u0 = np.array([1.0, 2.0, 0.5, -1.0, 0.3])
+    vf = orc.VectorField(name, 100, d, 1, f, jac, u0, np.array([8.0]), (0.0, 0.25))
+    N, dt = 4096, 2.0**-7
+    ens = pkg.EnsembleProblem(pkg.ODEProblem(name, vf.u0, vf.tspan, vf.p), perturb_scale=1e-2)
+    sol = pkg.solve(ens, pkg.EK1(order=q), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
+    assert sol.retcode == ["Success"] * N
+    assert sol.ctx.kernel_name(0) == "odef_jit_rows_fixed_every" and sol.ctx.kernel_name(1) == "odef_jit_bcast_fixed"
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    mf, ms, cs = sol.x_filt_mean(), sol.x_smooth_mean(), sol.x_smooth_cov()
+    for i in (0, 17, 4095):
+        ref = orc.solve(vf, orc.EK1(order=q), u0=u0s[i], tspan=vf.tspan, dt=dt)
+        np.testing.assert_allclose(mf[i][:, :d], ref.means(smoothed=False)[:, :d], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(ms[i][:, :d], ref.means(smoothed=True)[:, :d], rtol=1e-10, atol=1e-13)
+        assert P.cov_err(cs[i], ref.covs(smoothed=True)) < 1e-5
+    import os as _os
+
+    old = {k: _os.environ.get(k) for k in ("ODEF_FILTER_ROWS_MAX_N", "ODEF_SMOOTH_ROWS_MAX_N")}
+    try:
+        _os.environ["ODEF_FILTER_ROWS_MAX_N"] = "0"
+        _os.environ["ODEF_SMOOTH_ROWS_MAX_N"] = "0"
+        lane = pkg.solve(ens, pkg.EK1(order=q), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
+        assert lane.ctx.kernel_name(0) == "odef_jit_fixed_every" and lane.ctx.kernel_name(1) == "odef_jit_smooth_rows"
+        np.testing.assert_allclose(ms[..., :d], lane.x_smooth_mean()[..., :d], rtol=1e-9, atol=1e-12)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                _os.environ.pop(k, None)
+            else:
+                _os.environ[k] = v
 
 
 def test_user_vector_field_without_jacobian_uses_forward_mode(pkg):
