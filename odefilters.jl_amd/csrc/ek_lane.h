@@ -212,6 +212,8 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigne
   if constexpr (EVERY && !LAG) store_state<D, TRI>(P, 0, i0, lane, m, C, 0.0);
 
   double loglik = 0.0, gdiff = 0.0;
+  LogDetAcc lda;  // log det S of the steps, multiplied up (ek_math.h): det S = (prod |R_kk|)^2
+  lda.init();
   int chol_fix = 0;
   for (long n = 0; n < P.nsteps; ++n) {
     const GlobalTab tab{P.ptab + (size_t)uniform_load(P.tab_idx + n) * kTabStride};  // wave-uniform, scalar loads
@@ -239,6 +241,7 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigne
 #pragma unroll
     for (int k = 0; k < TRI; ++k) C[k] = C2[k];
     loglik += aux.loglik;
+    if (P.want_loglik) lda.mul(aux.det);
     gdiff = aux.sigma2_global;
     chol_fix += aux.chol_fix;
     if constexpr (EVERY && !LAG) {
@@ -248,7 +251,7 @@ __device__ inline void filter_fixed_lane(const FilterParams& P, long i0, unsigne
   }
   if constexpr (!EVERY) store_state<D, TRI>(P, 0, i0, lane, m, C, gdiff);
   if constexpr (EVERY && LAG) store_state<D, TRI>(P, P.nsteps, i0, lane, m, C, gdiff);  // the last record
-  P.loglik[i] = loglik;
+  P.loglik[i] = P.want_loglik ? loglik - lda.log_value() : loglik;  // -1/2 log det S = -log prod |R_kk|
   P.naccept[i] = (int)P.nsteps;
   P.nreject[i] = 0;
   P.nf[i] = (int)P.nsteps;
@@ -328,6 +331,8 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
   const Controller& ct = P.ctrl;
   double t = P.t0, h = P.dt0, qold = ct.qoldinit, q11 = 1.0, log_qold = log(ct.qoldinit), log_eest = 0.0;
   double loglik = 0.0, gdiff = 0.0;
+  LogDetAcc lda;
+  lda.init();
   int naccept = 0, nreject = 0, nsaved = 1, ret = 0;
   const long max_attempts = 20 * P.max_save + 1000;
   long attempts = 0;
@@ -382,7 +387,10 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
       for (int k = 0; k < D; ++k) m[k] = tab[kTabPIJ + k / d] * (tab[kTabPJ + k / d] * m[k]);
     }
     if (accepted) {
-      if (EEst < 1.0) loglik += aux.loglik;
+      if (EEst < 1.0) {
+        loglik += aux.loglik;
+        if (P.want_loglik) lda.mul(aux.det);
+      }
       if (qq <= ct.qsteady_max && qq >= ct.qsteady_min) qq = 1.0;
       qold = fmax(EEst, ct.qoldinit);
       log_qold = (EEst > ct.qoldinit) ? log_eest : log(ct.qoldinit);
@@ -403,7 +411,7 @@ __device__ inline void filter_adaptive_lane(const FilterParams& P, long i0, unsi
     if (accepted && !all_finite<D>(m)) { ret = 3; break; }
   }
   (void)qold;
-  P.loglik[i] = loglik;
+  P.loglik[i] = P.want_loglik ? loglik - lda.log_value() : loglik;
   P.naccept[i] = naccept;
   P.nreject[i] = nreject;
   P.nf[i] = naccept + nreject;

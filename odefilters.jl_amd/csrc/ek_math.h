@@ -49,9 +49,33 @@ __host__ __device__ constexpr int symidx(int i, int j) { return i >= j ? tri(i, 
 struct StepAux {
   double sigma2_local;   // cache.local_diffusion
   double sigma2_global;  // cache.global_diffusion
-  double loglik;         // cache.log_likelihood of this step
+  double loglik;         // cache.log_likelihood of this step WITHOUT its -1/2 log det S term when `det` carries that (d <= 4)
+  double det;            // d <= 4: sqrt(det S) (lane kernels: |prod R_kk|) or det S (row teams: prod D_k), see LogDetAcc; else 1
   double eest_num_sq[1]; // unused placeholder (keeps the struct POD-extensible)
   int chol_fix;          // number of non-positive pivots met by the Cholesky (QR-fallback cases)
+};
+
+// sum_n log(det_n) without a logarithm per step.  logpdf(measurement, 0) (src/perform_step.jl:66) needs log det S of every
+// step; a double-precision log is ~70 instructions -- a tenth of the row-team filter's step -- and only the SUM over the
+// steps is ever used (sol.log_likelihood).  So the determinants are multiplied up as (mantissa in [0.5, 1), binary exponent),
+// five instructions per factor (v_frexp_mant_f64, v_frexp_exp_i32_f64), and the logarithm is taken once, when the
+// trajectory's log-likelihood is stored.  A zero determinant (semi-definite S) gives -inf as log(0) did; the mantissa
+// product of 1 024 factors is good to 1e-13, i.e. to 1e-13 absolute in a sum of magnitude 1e4.
+struct LogDetAcc {
+  double m;
+  int e;
+  __device__ inline void init() {
+    m = 1.0;
+    e = 0;
+  }
+  __device__ inline void mul(double det) {
+    int ex;
+    m *= frexp(det, &ex);
+    e += ex;
+    m = frexp(m, &ex);
+    e += ex;
+  }
+  __device__ inline double log_value() const { return log(m) + (double)e * 0.69314718055994530942; }
 };
 
 // sqrt(x) and 1 / sqrt(x) together, for x > 0: v_rsq_f64 seed and two coupled Goldschmidt steps plus one residual correction each -- 14 instructions where a
@@ -581,12 +605,12 @@ struct EKStep {
       else if (want_loglik) logacc += log(fabs(R[r][r]));
     }
     if (want_loglik) {
-      if constexpr (d <= 4) logacc = log(fabs(detprod));
-      // logpdf(measurement, 0) (src/perform_step.jl:66)
+      // logpdf(measurement, 0) (src/perform_step.jl:66); d <= 4: log det S = 2 log |prod R_kk| is left to the caller's LogDetAcc
       aux.loglik = -0.5 * (zSz + 2.0 * logacc + d * 1.8378770664093453);
     } else {
       aux.loglik = 0.0;
     }
+    aux.det = (d <= 4) ? fabs(detprod) : 1.0;
 
     if (fixed_diffusion) {
       // FixedDiffusion (src/diffusions.jl:11-36): running mean of z' S^-1 z / d;  MAPFixedDiffusion (:46-68)

@@ -8,7 +8,7 @@
 #include <cstddef>
 #define __device__
 #define __host__
-using std::fabs; using std::fmax; using std::fmin; using std::sqrt; using std::pow; using std::log; using std::exp;
+using std::fabs; using std::fmax; using std::fmin; using std::sqrt; using std::pow; using std::log; using std::exp; using std::frexp;
 #elif defined(__HIPCC_RTC__)
 // hiprtc-style compilation without system headers (kept working although csrc/jit.hip now uses a hipcc child
 // process): the HIP device API and the math functions are built in; the few traits the math headers use are declared here.

@@ -281,11 +281,12 @@ struct RowsStep {
       else if (want_loglik) logacc += log(sd[r]);
     }
     if (want_loglik) {
-      if constexpr (d <= 4) logacc = log(detprod);
-      aux.loglik = -0.5 * (zSz + logacc + d * 1.8378770664093453);  // logpdf(measurement, 0) (src/perform_step.jl:66)
+      // logpdf(measurement, 0) (src/perform_step.jl:66); d <= 4: log det S = log prod D_k is left to the caller's LogDetAcc
+      aux.loglik = -0.5 * (zSz + logacc + d * 1.8378770664093453);
     } else {
       aux.loglik = 0.0;
     }
+    aux.det = (d <= 4) ? detprod : 1.0;
     if (fixed_diffusion) {  // FixedDiffusion / MAPFixedDiffusion (src/diffusions.jl:11-36, 46-68)
       const double diffusion_t = zSz * (1.0 / d);
       aux.sigma2_local = diffusion_t;
@@ -420,6 +421,8 @@ __device__ inline void rows_filter_fixed(const FilterParams& P, const RowsTeam& 
   RowsScale<d, NB> sc;
   int cur_tab = -1;
   double loglik = 0.0, gdiff = 0.0;
+  LogDetAcc lda;
+  lda.init();
   int chol_fix = 0;
   for (long n = 0; n < P.nsteps; ++n) {
     const int ti = uniform_load(P.tab_idx + n);  // wave-uniform, scalar load
@@ -432,6 +435,7 @@ __device__ inline void rows_filter_fixed(const FilterParams& P, const RowsTeam& 
     aux.chol_fix = 0;
     S::run(P.pc, lc, sc, pl, P.fixed_diffusion, P.want_loglik != 0, (int)n, gdiff, lds, m, xr, es, aux);
     loglik += aux.loglik;
+    if (P.want_loglik) lda.mul(aux.det);
     gdiff = aux.sigma2_global;
     chol_fix += aux.chol_fix;
     if constexpr (EVERY) sink.put(n + 1, tm.valid, false, m, xr, gdiff, 0.0);
@@ -446,7 +450,7 @@ __device__ inline void rows_filter_fixed(const FilterParams& P, const RowsTeam& 
   (void)chol_fix;
   const bool bad = tv::team_any(tv::nonfinite_flag(m));
   if (tm.valid && tv::is_lane0()) {
-    P.loglik[i] = loglik;
+    P.loglik[i] = P.want_loglik ? loglik - 0.5 * lda.log_value() : loglik;
     P.naccept[i] = (int)P.nsteps;
     P.nreject[i] = 0;
     P.nf[i] = (int)P.nsteps;
@@ -488,6 +492,8 @@ __device__ inline void rows_filter_adaptive(const FilterParams& P, const RowsTea
   const Controller& ct = P.ctrl;
   double t = P.t0, h = P.dt0, qold = ct.qoldinit, log_qold = log(ct.qoldinit), log_eest = 0.0;
   double loglik = 0.0, gdiff = 0.0;
+  LogDetAcc lda;
+  lda.init();
   int naccept = 0, nreject = 0, nsaved = 1, ret = 0;
   const long max_attempts = 20 * P.max_save + 1000;
   long attempts = 0;
@@ -554,7 +560,10 @@ __device__ inline void rows_filter_adaptive(const FilterParams& P, const RowsTea
         sink.stage_cov(lds, S::LD, xr);  // the exchange rows hold the rejected candidate
       }
       if (accepted) {
-        if (EEst < 1.0) loglik += aux.loglik;
+        if (EEst < 1.0) {
+          loglik += aux.loglik;
+          if (P.want_loglik) lda.mul(aux.det);
+        }
         if (qq <= ct.qsteady_max && qq >= ct.qsteady_min) qq = 1.0;
         qold = fmax(EEst, ct.qoldinit);
         log_qold = (EEst > ct.qoldinit) ? log_eest : log(ct.qoldinit);
@@ -582,7 +591,7 @@ __device__ inline void rows_filter_adaptive(const FilterParams& P, const RowsTea
   }
   (void)qold;
   if (tm.valid && tv::is_lane0()) {
-    P.loglik[i] = loglik;
+    P.loglik[i] = P.want_loglik ? loglik - 0.5 * lda.log_value() : loglik;
     P.naccept[i] = naccept;
     P.nreject[i] = nreject;
     P.nf[i] = naccept + nreject;
