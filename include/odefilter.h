@@ -79,7 +79,8 @@ typedef enum {
   ODEF_RHS_LOTKA_VOLTERRA = 2, /* u' = (a u1 - b u1 u2, -c u2 + d u1 u2), p = (a,b,c,d) */
   ODEF_RHS_VANDERPOL = 3,      /* u' = (u2, mu((1-u1^2)u2 - u1)), p = (mu) */
   ODEF_RHS_LINEAR = 4,         /* u_i' = p_i u_i, d = 2 */
-  ODEF_RHS_PLEIADES = 5        /* 7-body, d = 28, no parameters; workgroup-per-trajectory kernels, fixed steps */
+  ODEF_RHS_PLEIADES = 5,       /* 7-body, d = 28, no parameters; workgroup-per-trajectory kernels (matrix cores) */
+  ODEF_RHS_LORENZ96 = 6        /* u_i' = (u_{i+1} - u_{i-2}) u_{i-1} - u_i + F, d = 16, p = (F); workgroup-per-trajectory kernels */
 } odef_rhs;
 typedef enum { ODEF_SAVE_FINAL = 0, ODEF_SAVE_EVERYSTEP = 1 } odef_save_mode;
 typedef enum {

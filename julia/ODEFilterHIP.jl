@@ -19,7 +19,7 @@ struct OdefConfig                      # odef_config, 56 bytes
     device::Int32; want_loglik::Int32; n_traj::Int64
 end
 
-const RHS_IDS = Dict(:fhn => 0, :lorenz63 => 1, :lotka_volterra => 2, :vanderpol => 3, :linear => 4, :pleiades => 5)
+const RHS_IDS = Dict(:fhn => 0, :lorenz63 => 1, :lotka_volterra => 2, :vanderpol => 3, :linear => 4, :pleiades => 5, :lorenz96 => 6)
 const DIFFUSIONS = Dict(:dynamic => 0, :fixed => 1, :fixedMAP => 2)   # src/caches.jl:89-96 (the MV models are not on the device)
 const F_MEAN, F_COV_TRIL, F_DIFFUSION, F_T, F_LOGLIK, F_NACCEPT, F_NREJECT, F_NF, F_NJAC, F_NSAVED,
       F_RETCODE, F_SMOOTH_MEAN, F_SMOOTH_COV_TRIL = 0:12

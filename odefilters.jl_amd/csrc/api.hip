@@ -33,7 +33,7 @@ struct Buf {
 };
 
 struct RhsInfo { int d, np; };
-const RhsInfo kRhs[] = {{2, 3}, {3, 3}, {2, 4}, {2, 1}, {2, 2}, {28, 0}};
+const RhsInfo kRhs[] = {{2, 3}, {3, 3}, {2, 4}, {2, 1}, {2, 2}, {28, 0}, {16, 1}};
 
 }  // namespace
 
@@ -65,6 +65,7 @@ struct odef_ctx {
   bool adaptive = false;
   bool solved = false;
   bool team_path = false;   // workgroup-per-trajectory kernels (large state dimension)
+  const TeamLaunch* team = nullptr;  // ... and their launch functions for this vector field
   JitModule* jit = nullptr; // run-time compiled vector field (rhs_id >= 100); owned by the registry in jit.hip
   double* d_ws = nullptr;   // per-trajectory workspace of the team kernels
   double* d_stage = nullptr;  // trajectory-major stage of the covariance records (D = 168 smoother, record_stage.h)
@@ -308,7 +309,7 @@ int odef_create(odef_ctx** out, const odef_config* cfg) {
   if (cfg->rhs_id >= kJitFirstId) {
     if (!jit_lookup(cfg->rhs_id, &ri.d, &ri.np)) return fail(nullptr, "odef_create: unknown run-time rhs_id %d", cfg->rhs_id);
   } else {
-    if (cfg->rhs_id < 0 || cfg->rhs_id > ODEF_RHS_PLEIADES) return fail(nullptr, "odef_create: unknown rhs_id %d", cfg->rhs_id);
+    if (cfg->rhs_id < 0 || cfg->rhs_id > ODEF_RHS_LORENZ96) return fail(nullptr, "odef_create: unknown rhs_id %d", cfg->rhs_id);
     ri = kRhs[cfg->rhs_id];
   }
   if (cfg->d != ri.d) return fail(nullptr, "odef_create: rhs %d has dimension %d, got d=%d", cfg->rhs_id, ri.d, cfg->d);
@@ -335,7 +336,8 @@ int odef_create(odef_ctx** out, const odef_config* cfg) {
   else if (hipGetDevice(&c->device) != hipSuccess) c->device = 0;
   if (c->device >= ndev) { delete c; return fail(nullptr, "odef_create: device %d not present (%d devices)", cfg->device, ndev); }
   build_prior(c->q, c->pc);
-  c->team_path = (cfg->rhs_id == ODEF_RHS_PLEIADES);
+  c->team = team_launch(cfg->rhs_id);
+  c->team_path = c->team != nullptr;
   hipError_t e = hipSetDevice(c->device);
   if (e == hipSuccess && cfg->rhs_id >= kJitFirstId) {
     std::string jerr;
@@ -591,8 +593,8 @@ int odef_solve_fixed(odef_ctx* c, const double* tgrid, int64_t n_t) {
   P.t0 = c->t0;
   int rc;
   if (c->team_path) {
-    const char* path = getenv("ODEF_PLEIADES_PATH");  // "team": the global-workspace kernel, for A/B comparison
-    if (path && std::strcmp(path, "team") == 0) {
+    const char* path = getenv("ODEF_PLEIADES_PATH");  // "team": the global-workspace kernel, for A/B comparison (Pleiades only)
+    if (c->cfg.rhs_id == ODEF_RHS_PLEIADES && path && std::strcmp(path, "team") == 0) {
       if (ensure_ws(c, (size_t)c->cfg.n_traj * team_filter_ws_doubles(c->d, c->q))) return -1;
       TeamFilterParams TP{P, c->d_ws};
       HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -605,7 +607,7 @@ int odef_solve_fixed(odef_ctx* c, const double* tgrid, int64_t n_t) {
         if (have < (size_t)(nsteps + 1) * per_rec) have = 0;
       }
       HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-      rc = launch_filter_pleiades_tiles(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 0, have ? c->d_stage : nullptr, have);
+      rc = c->team->filter(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 0, have ? c->d_stage : nullptr, have);
     }
   } else {
     // one lane per trajectory: the per-field buffer descriptors carry 32-bit sizes
@@ -664,7 +666,7 @@ int odef_solve_adaptive(odef_ctx* c, double t1, double abstol, double reltol, do
     note_kernel("odef_jit_adaptive");
     rc = jit_launch(c->jit->adaptive, (unsigned)((P.N + 63) / 64), 1, &P, c->stream);
   } else {
-    rc = c->team_path ? launch_filter_pleiades_tiles(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 1)
+    rc = c->team_path ? c->team->filter(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 1, nullptr, 0)
                       : launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 1, P, c->stream);
   }
   if (rc) return fail(c, "odef_solve_adaptive: no kernel for rhs %d order %d", c->cfg.rhs_id, c->q);
@@ -700,7 +702,7 @@ int odef_smooth(odef_ctx* c) {
     HIPCHK(c, hipMemsetAsync(S.smean, 0, c->f[ODEF_F_SMOOTH_MEAN].valid, c->stream));
     HIPCHK(c, hipMemsetAsync(S.scov, 0, c->f[ODEF_F_SMOOTH_COV_TRIL].valid, c->stream));
   }
-  if (c->team_path && ensure_ws(c, (size_t)c->cfg.n_traj * team_smooth_ws_doubles(c->d, c->q))) return -1;
+  if (c->team_path && ensure_ws(c, (size_t)c->cfg.n_traj * c->team->smooth_ws(c->q))) return -1;
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   int rc;
   if (c->jit)
@@ -730,9 +732,9 @@ int odef_smooth(odef_ctx* c) {
       }
       const size_t tri = (size_t)c->D * (c->D + 1) / 2;
       const size_t have = n_rec < 3 ? 0 : ensure_stage(c, n_rec - 1, (size_t)S.N * ((tri + 15) / 16 * 16));
-      if (have) rc = launch_smooth_d28_staged(c->q, S, n_rec, c->d_ws, c->d_stage, have, c->stream);
+      if (have) rc = c->team->smooth_staged(c->q, S, n_rec, c->d_ws, c->d_stage, have, c->stream);
     }
-    if (rc == -4) rc = launch_smooth_d28(c->q, S, c->d_ws, c->stream);
+    if (rc == -4) rc = c->team->smooth(c->q, S, c->d_ws, c->stream);
   } else
     rc = launch_smooth(c->d, c->q, S, c->stream);
   if (rc) return fail(c, "odef_smooth: no kernel for d %d order %d", c->d, c->q);
@@ -784,12 +786,12 @@ int odef_dense_output(odef_ctx* c, const double* tq, int64_t n_q, int smoothed) 
   P.n_q = (long)n_q;
   P.qmean = (double*)c->f[ODEF_F_DENSE_MEAN].ptr;
   P.qcov = (double*)c->f[ODEF_F_DENSE_COV_TRIL].ptr;
-  if (c->team_path && ensure_ws(c, (size_t)dense_d28_grid(P.N * P.n_q) * team_smooth_ws_doubles(c->d, c->q))) return -1;
+  if (c->team_path && ensure_ws(c, (size_t)dense_d28_grid(P.N * P.n_q) * c->team->smooth_ws(c->q))) return -1;
   const long rows_tpb = c->jit ? 64 / c->jit->rows_team : 1;
   const int rc = c->jit ? (c->jit->posterior    ? jit_launch(c->jit->dense, (unsigned)((P.N + 63) / 64), (unsigned)P.n_q, &P, c->stream)
                            : c->jit->dense_rows ? jit_launch(c->jit->dense_rows, (unsigned)((P.N * P.n_q + rows_tpb - 1) / rows_tpb), 1, &P, c->stream)
                                                 : -3)
-                 : c->team_path ? launch_dense_d28(c->q, P, c->d_ws, c->stream)
+                 : c->team_path ? c->team->dense(c->q, P, c->d_ws, c->stream)
                  : c->d == 2 ? launch_dense_d2(c->q, P, c->stream) : c->d == 3 ? launch_dense_d3(c->q, P, c->stream) : -3;
   if (rc) return fail(c, "odef_dense_output: no kernel for d %d order %d", c->d, c->q);
   HIPCHK(c, hipGetLastError());
@@ -825,12 +827,12 @@ int odef_sample(odef_ctx* c, int64_t n_samples, uint64_t seed, double noise_scal
   S.noise_scale = noise_scale;
   S.samples = (double*)c->f[ODEF_F_SAMPLES].ptr;
   if (c->adaptive) HIPCHK(c, hipMemsetAsync(S.samples, 0, c->f[ODEF_F_SAMPLES].valid, c->stream));  // unused slots stay defined
-  if (c->team_path && ensure_ws(c, (size_t)dense_d28_grid(S.N * S.n_samples) * team_smooth_ws_doubles(c->d, c->q))) return -1;
+  if (c->team_path && ensure_ws(c, (size_t)dense_d28_grid(S.N * S.n_samples) * c->team->smooth_ws(c->q))) return -1;
   const long rows_tpb = c->jit ? 64 / c->jit->rows_team : 1;
   const int rc = c->jit ? (c->jit->posterior     ? jit_launch(c->jit->sample, (unsigned)((S.N + 63) / 64), (unsigned)S.n_samples, &S, c->stream)
                            : c->jit->sample_rows ? jit_launch(c->jit->sample_rows, (unsigned)((S.N * S.n_samples + rows_tpb - 1) / rows_tpb), 1, &S, c->stream)
                                                  : -3)
-                 : c->team_path ? launch_sample_d28(c->q, S, c->d_ws, c->stream)
+                 : c->team_path ? c->team->sample(c->q, S, c->d_ws, c->stream)
                  : c->d == 2 ? launch_sample_d2(c->q, S, c->stream) : c->d == 3 ? launch_sample_d3(c->q, S, c->stream) : -3;
   if (rc) return fail(c, "odef_sample: no kernel for d %d order %d", c->d, c->q);
   HIPCHK(c, hipGetLastError());
@@ -864,12 +866,12 @@ int odef_dense_sample(odef_ctx* c, const double* tq, int64_t n_q, int64_t n_samp
   S.seed = (unsigned long long)seed;
   S.noise_scale = noise_scale;
   S.samples = (double*)c->f[ODEF_F_SAMPLES].ptr;
-  if (c->team_path && ensure_ws(c, (size_t)dense_d28_grid(S.N * S.n_samples) * team_smooth_ws_doubles(c->d, c->q))) return -1;
+  if (c->team_path && ensure_ws(c, (size_t)dense_d28_grid(S.N * S.n_samples) * c->team->smooth_ws(c->q))) return -1;
   const long rows_tpb = c->jit ? 64 / c->jit->rows_team : 1;
   const int rc = c->jit ? (c->jit->posterior     ? jit_launch(c->jit->sample, (unsigned)((S.N + 63) / 64), (unsigned)S.n_samples, &S, c->stream)
                            : c->jit->sample_rows ? jit_launch(c->jit->sample_rows, (unsigned)((S.N * S.n_samples + rows_tpb - 1) / rows_tpb), 1, &S, c->stream)
                                                  : -3)
-                 : c->team_path ? launch_sample_d28(c->q, S, c->d_ws, c->stream)
+                 : c->team_path ? c->team->sample(c->q, S, c->d_ws, c->stream)
                  : c->d == 2 ? launch_sample_d2(c->q, S, c->stream) : c->d == 3 ? launch_sample_d3(c->q, S, c->stream) : -3;
   if (rc) return fail(c, "odef_dense_sample: no kernel for d %d order %d", c->d, c->q);
   HIPCHK(c, hipGetLastError());
@@ -1315,6 +1317,9 @@ int launch_filter(int rhs, int q, int ek1, int adaptive, const FilterParams& P, 
     case ODEF_RHS_LINEAR: return launch_filter_linear(q, ek1, adaptive, P, s);
     default: return -2;
   }
+}
+const TeamLaunch* team_launch(int rhs_id) {
+  return rhs_id == ODEF_RHS_PLEIADES ? team_pleiades() : rhs_id == ODEF_RHS_LORENZ96 ? team_lorenz96() : nullptr;
 }
 int launch_smooth(int d, int q, const SmoothParams& P, hipStream_t s) {
   if (d == 2) return launch_smooth_d2(q, P, s);

@@ -220,13 +220,16 @@ inline bool pleiades_filter_tiles() {
   const char* e = getenv("ODEF_PLEIADES_FILTER");
   return e && e[0] == 't';
 }
-struct LaunchTilesFilter {
+// VALU_ALTERNATES: the register-tiled VALU kernels of round 1 are instantiated beside the matrix-core ones (Pleiades only: their
+// 7 x 7 tiles are cut for d = 28); every other workgroup-per-trajectory field gets the matrix-core kernels alone
+template <bool VALU_ALTERNATES = true>
+struct LaunchTilesFilterT {
   const FilterParams& P;
   hipStream_t s;
   int adaptive = 0;
   template <class RHS, int q, bool EK1>
   void operator()() {
-    if (!pleiades_filter_tiles()) {
+    if (!VALU_ALTERNATES || !pleiades_filter_tiles()) {
       note_kernel("odef::ek_filter_mfma%s_kernel<odef::%s, %d, %s>", adaptive ? "_adaptive" : "", RHS::name, q, tf(EK1));
       if (adaptive)
         hipLaunchKernelGGL((ek_filter_mfma_adaptive_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kMfBlock), 0, s, P);
@@ -234,13 +237,16 @@ struct LaunchTilesFilter {
         hipLaunchKernelGGL((ek_filter_mfma_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kMfBlock), 0, s, P);
       return;
     }
-    note_kernel("odef::ek_filter_tiles%s_kernel<odef::%s, %d, %s>", adaptive ? "_adaptive" : "", RHS::name, q, tf(EK1));
-    if (adaptive)
-      hipLaunchKernelGGL((ek_filter_tiles_adaptive_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kTilesBlock), 0, s, P);
-    else
-      hipLaunchKernelGGL((ek_filter_tiles_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kTilesBlock), 0, s, P);
+    if constexpr (VALU_ALTERNATES) {
+      note_kernel("odef::ek_filter_tiles%s_kernel<odef::%s, %d, %s>", adaptive ? "_adaptive" : "", RHS::name, q, tf(EK1));
+      if (adaptive)
+        hipLaunchKernelGGL((ek_filter_tiles_adaptive_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kTilesBlock), 0, s, P);
+      else
+        hipLaunchKernelGGL((ek_filter_tiles_kernel<RHS, q, EK1>), dim3(team_grid(P.N)), dim3(kTilesBlock), 0, s, P);
+    }
   }
 };
+using LaunchTilesFilter = LaunchTilesFilterT<true>;
 
 struct LaunchTeamFilter {
   const TeamFilterParams& TP;
@@ -461,22 +467,29 @@ struct LaunchTeamSmoothSweeps {
     hipLaunchKernelGGL((rts_smooth_sweeps_kernel<d, q>), dim3(team_grid(P.N)), dim3(64 * W::DPB), lds_bytes, s, P, ws);
   }
 };
-struct LaunchTeamSmooth {
+template <bool VALU_ALTERNATES = true>
+struct LaunchTeamSmoothT {
   const SmoothParams& P;
   double* ws;
   hipStream_t s;
   template <int d, int q>
   void operator()() {
     // (the workspace kernel of the pass: the dominant one also when the sweeps run in a kernel of their own)
-    note_kernel(pleiades_smooth_team() ? "odef::rts_smooth_team_kernel<%d, %d>" : P.split_mode != 0 ? "odef::rts_smooth_mfma_kernel<%d, %d, true>" : "odef::rts_smooth_mfma_kernel<%d, %d, false>", d, q);
-    if (pleiades_smooth_team())
-      hipLaunchKernelGGL((rts_smooth_team_kernel<d, q>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
-    else if (P.split_mode != 0)
+    const bool team = VALU_ALTERNATES && pleiades_smooth_team();
+    note_kernel(team ? "odef::rts_smooth_team_kernel<%d, %d>" : P.split_mode != 0 ? "odef::rts_smooth_mfma_kernel<%d, %d, true>" : "odef::rts_smooth_mfma_kernel<%d, %d, false>", d, q);
+    if constexpr (VALU_ALTERNATES) {
+      if (team) {
+        hipLaunchKernelGGL((rts_smooth_team_kernel<d, q>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
+        return;
+      }
+    }
+    if (P.split_mode != 0)
       hipLaunchKernelGGL((rts_smooth_mfma_kernel<d, q, true>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
     else
       hipLaunchKernelGGL((rts_smooth_mfma_kernel<d, q, false>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
   }
 };
+using LaunchTeamSmooth = LaunchTeamSmoothT<true>;
 
 struct LaunchFilter {
   const FilterParams& P;

@@ -169,11 +169,13 @@ struct MfLds {
   //   scratch of chol(W)    over H0 | M0 once W is built: two diagonal blocks (+ pivots), the block below, L21, W11, W22
   //   WL | scratch of Sm    W_S = L^-1 of the innovation covariance [32][LDP], then the blocks of Sm and L21
   static constexpr int LDd = d + 1;
-  static constexpr int H0 = R0_size, M0 = H0 + d * d, WM = M0 + d * d;
   static constexpr int CW11 = R0_size, CW22 = CW11 + 272, CW21 = CW22 + 272, CWL = CW21 + 256, CWW1 = CWL + 256, CWW2 = CWW1 + 256;
+  // W sits behind H0 | M0 AND behind the scratch of its own factorisation (six 16 x 16 blocks, sized for d <= 32 whatever d is:
+  // at d = 28 the two coincide, a smaller d leaves a gap)
+  static constexpr int H0 = R0_size, M0 = H0 + d * d, WM = (M0 + d * d > CWW2 + 256) ? M0 + d * d : CWW2 + 256;
   static_assert(CWW2 + 256 <= WM, "the scratch of chol(W) must not reach W itself");
   static constexpr int WL = R0_size, SB11 = WL + 32 * LDP, SB22 = SB11 + 272, SB21 = SB22 + 272, L21 = SB21 + 256;
-  static constexpr int B_need1 = 2 * d * d + d * LDd, B_need2 = L21 + 256 - R0_size;
+  static constexpr int B_need1 = (WM - R0_size) + d * LDd, B_need2 = L21 + 256 - R0_size;
   static constexpr int B_size = B_need1 > B_need2 ? B_need1 : B_need2;
   static constexpr int HS0 = R0_size + B_size;  // [32][LDP]: H0' in padded indices (k = state column, a = measurement)
   static constexpr int MV = HS0 + 32 * LDP, MT = MV + D, MP = MT + D, Z = MP + D, YV = Z + 32, UP = YV + 32;  // z: d values + zeros up to 32

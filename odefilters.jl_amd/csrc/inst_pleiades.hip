@@ -1,4 +1,4 @@
-#include "ek_kernels.h"
+#include "team_launch_impl.h"
 namespace odef {
 int launch_filter_pleiades(int q, int ek1, const TeamFilterParams& TP, hipStream_t s) {
   LaunchTeamFilter f{TP, s};
@@ -21,105 +21,15 @@ static int launch_filter_pleiades_tiles_order(int q, int ek1, const FilterParams
     default: return -2;
   }
 }
-// grid.z of the staging kernels counts records: at most 65 535 per launch
-static void launch_stage_copy(bool in, const double* src, double* dst, long N, long TRI, long ld, long n_rec, hipStream_t s) {
-  const dim3 tiles((unsigned)((N + kStageTile - 1) / kStageTile), (unsigned)((TRI + kStageTile - 1) / kStageTile));
-  for (long r0 = 0; r0 < n_rec; r0 += 65535) {
-    const unsigned nz = (unsigned)(n_rec - r0 < 65535 ? n_rec - r0 : 65535);
-    const size_t so = (size_t)r0 * (size_t)N * (size_t)(in ? TRI : ld), dof = (size_t)r0 * (size_t)N * (size_t)(in ? ld : TRI);
-    if (in)
-      hipLaunchKernelGGL(stage_in_kernel<kStageTile>, dim3(tiles.x, tiles.y, nz), dim3(256), 0, s, src + so, dst + dof, N, TRI, ld);
-    else
-      hipLaunchKernelGGL(stage_out_kernel<kStageTile>, dim3(tiles.x, tiles.y, nz), dim3(256), 0, s, src + so, dst + dof, N, TRI, ld);
-  }
-}
-// Fixed grid on the matrix-core kernel with every step saved: when `stage` holds all nsteps + 1 records the kernel writes
-// its covariance records there (trajectory-major, whole lines) and one transposition pass moves them to P.cov.
 int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles) {
-  const long D = 28L * (q + 1), TRI = D * (D + 1) / 2, ld = stage_record_ld(TRI), n_rec = P.nsteps + 1;
-  if (adaptive || !P.everystep || pleiades_filter_tiles() || !stage || (size_t)n_rec * (size_t)P.N * (size_t)ld > stage_doubles)
-    return launch_filter_pleiades_tiles_order(q, ek1, P, s, adaptive);
-  FilterParams PS = P;
-  PS.cov_stage = stage;
-  PS.stage_ld = ld;
-  const int rc = launch_filter_pleiades_tiles_order(q, ek1, PS, s, 0);
-  if (rc) return rc;
-  launch_stage_copy(false, stage, P.cov, P.N, TRI, ld, n_rec, s);
-  return 0;
+  return team_filter_staged<28>(q, ek1, P, s, adaptive, stage, stage_doubles, pleiades_filter_tiles(), launch_filter_pleiades_tiles_order);
 }
-int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s) {
-  LaunchTeamSmooth f{P, ws, s};
-  return dispatch_smooth_order<28>(q, f);
-}
-// The same pass with the covariance records staged trajectory-major (record_stage.h), in blocks of as many records as
-// `stage` holds, from the last record down: [records in] -> smoother launch over the block (carried state in the workspace)
-// -> [records out].  `n_rec`: number of save slots in use (fixed grids: n_save; adaptive: the largest nsaved of the
-// ensemble -- every trajectory joins in at the block that holds its own last record).  stage_doubles must hold at
-// least two records.
+int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s) { return team_smooth_inplace<28, true>(q, P, ws, s); }
 int launch_smooth_d28_staged(int q, const SmoothParams& P0, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s) {
-  const long n = n_rec, N = P0.N;
-  const long D = 28L * (q + 1), TRI = D * (D + 1) / 2, ld = stage_record_ld(TRI);
-  const size_t per_rec = (size_t)N * (size_t)ld;
-  const long cap = (long)(stage_doubles / per_rec);
-  if (n < 2 || n > P0.n_save || cap < 2 || pleiades_smooth_team()) return -4;  // the caller runs the pass on the records in place
-  // record 0 is never smoothed (src/smoothing.jl:11) and never staged: copied here (a trajectory that has no other record
-  // is not visited by any launch)
-  if (hipMemcpyAsync(P0.scov, P0.cov, (size_t)TRI * (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return -5;
-  if (hipMemcpyAsync(P0.smean, P0.mean, (size_t)D * (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return -5;
-  long top = n - 1;  // highest record not yet through the stage
-  while (top >= 1) {
-    const long hi = top, lo = hi - cap + 1 > 1 ? hi - cap + 1 : 1;
-    SmoothParams P = P0;
-    P.stage = stage;
-    P.stage_s0 = lo;
-    P.stage_hi = hi;
-    P.stage_ld = ld;
-    launch_stage_copy(true, P0.cov + (size_t)lo * TRI * N, stage, N, TRI, ld, hi - lo + 1, s);
-    if (!pleiades_smooth_split()) {
-      LaunchTeamSmooth f{P, ws, s};
-      const int rc = dispatch_smooth_order<28>(q, f);
-      if (rc) return rc;
-    } else {
-      // one kernel per phase and record: [set up the block] then, record by record from the top,
-      // [finish record r + 1 | begin record r] -> [sweeps of record r with the factor in LDS]; trajectories that do not have
-      // the record (adaptive solves) or repeat a save time skip their part inside the kernels
-      P.split_mode = 1;
-      P.split_sc = P.split_sa = -1;
-      {
-        LaunchTeamSmooth f{P, ws, s};
-        const int rc = dispatch_smooth_order<28>(q, f);
-        if (rc) return rc;
-      }
-      const long r_hi = hi < n - 2 ? hi : n - 2, r_lo = lo;
-      P.split_mode = 2;
-      for (long r = r_hi; r >= r_lo - 1; --r) {
-        P.split_sc = r + 1 <= r_hi ? r + 1 : -1;
-        P.split_sa = r >= r_lo ? r : -1;
-        {
-          LaunchTeamSmooth f{P, ws, s};
-          const int rc = dispatch_smooth_order<28>(q, f);
-          if (rc) return rc;
-        }
-        if (P.split_sa >= 0) {
-          LaunchTeamSmoothSweeps g{P, ws, s};
-          const int rc = dispatch_smooth_order<28>(q, g);
-          if (rc || g.rc) return rc ? rc : g.rc;
-        }
-      }
-    }
-    launch_stage_copy(false, stage, P0.scov + (size_t)lo * TRI * N, N, TRI, ld, hi - lo + 1, s);
-    top = lo - 1;
-  }
-  return 0;
+  return team_smooth_staged<28, true>(q, P0, n_rec, ws, stage, stage_doubles, s);
 }
-int launch_dense_d28(int q, const DenseParams& P, double* ws, hipStream_t s) {
-  LaunchTeamDense f{P, ws, s};
-  return dispatch_smooth_order<28>(q, f);
-}
-int launch_sample_d28(int q, const SampleParams& P, double* ws, hipStream_t s) {
-  LaunchTeamSample f{P, ws, s};
-  return dispatch_smooth_order<28>(q, f);
-}
+int launch_dense_d28(int q, const DenseParams& P, double* ws, hipStream_t s) { return team_dense<28>(q, P, ws, s); }
+int launch_sample_d28(int q, const SampleParams& P, double* ws, hipStream_t s) { return team_sample<28>(q, P, ws, s); }
 long dense_d28_grid(long items) { return items < kDenseMfmaMaxGrid ? items : kDenseMfmaMaxGrid; }
 size_t team_filter_ws_doubles(int d, int q) {
   if (d != 28) return 0;
@@ -132,16 +42,12 @@ size_t team_filter_ws_doubles(int d, int q) {
     default: return 0;
   }
 }
-size_t team_smooth_ws_doubles(int d, int q) {
-  if (d != 28) return 0;
-  switch (q) {
-    // the larger of the two smoothers' workspaces (smooth_team.h: 3 D x D matrices; smooth_mfma.h: 7 padded ones)
-    case 1: return MfmaSmoothWs<28, 2>::size > (size_t)SmoothWs<28, 2>::size ? MfmaSmoothWs<28, 2>::size : (size_t)SmoothWs<28, 2>::size;
-    case 2: return MfmaSmoothWs<28, 3>::size > (size_t)SmoothWs<28, 3>::size ? MfmaSmoothWs<28, 3>::size : (size_t)SmoothWs<28, 3>::size;
-    case 3: return MfmaSmoothWs<28, 4>::size > (size_t)SmoothWs<28, 4>::size ? MfmaSmoothWs<28, 4>::size : (size_t)SmoothWs<28, 4>::size;
-    case 4: return MfmaSmoothWs<28, 5>::size > (size_t)SmoothWs<28, 5>::size ? MfmaSmoothWs<28, 5>::size : (size_t)SmoothWs<28, 5>::size;
-    case 5: return MfmaSmoothWs<28, 6>::size > (size_t)SmoothWs<28, 6>::size ? MfmaSmoothWs<28, 6>::size : (size_t)SmoothWs<28, 6>::size;
-    default: return 0;
-  }
+static size_t smooth_ws_pleiades(int q) { return team_smooth_ws<28, true>(q); }
+static int filter_pleiades(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles) {
+  return launch_filter_pleiades_tiles(q, ek1, P, s, adaptive, stage, stage_doubles);
+}
+const TeamLaunch* team_pleiades() {  // (a function-local table: a namespace-scope constant would also be emitted for the device)
+  static const TeamLaunch t = {28, filter_pleiades, launch_smooth_d28, launch_smooth_d28_staged, launch_dense_d28, launch_sample_d28, smooth_ws_pleiades};
+  return &t;
 }
 }  // namespace odef

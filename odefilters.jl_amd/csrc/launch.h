@@ -30,7 +30,21 @@ int launch_dense_d2(int q, const DenseParams& P, hipStream_t s);
 int launch_dense_d3(int q, const DenseParams& P, hipStream_t s);
 int launch_sample_d2(int q, const SampleParams& P, hipStream_t s);
 int launch_sample_d3(int q, const SampleParams& P, hipStream_t s);
-// workgroup-per-trajectory path (Pleiades, d = 28)
+// workgroup-per-trajectory path: the launch functions of one vector field (team_launch_impl.h instantiated per field) ...
+struct TeamLaunch {
+  int d;
+  // fixed grid (adaptive = 0; every-step records through `stage` when all of them fit) or adaptive solve on the matrix-core filter
+  int (*filter)(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles);
+  int (*smooth)(int q, const SmoothParams& P, double* ws, hipStream_t s);  // records in place
+  int (*smooth_staged)(int q, const SmoothParams& P, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s);
+  int (*dense)(int q, const DenseParams& P, double* ws, hipStream_t s);    // ws: dense_d28_grid(items) x smooth_ws(q) doubles
+  int (*sample)(int q, const SampleParams& P, double* ws, hipStream_t s);
+  size_t (*smooth_ws)(int q);  // doubles of workspace per trajectory (smoother) / per grid slot (dense output, sampling)
+};
+const TeamLaunch* team_pleiades();  // d = 28 (BASELINE config 4)
+const TeamLaunch* team_lorenz96();  // d = 16: the same kernels on a second shape
+const TeamLaunch* team_launch(int rhs_id);  // nullptr: the field runs on the lane / row-team kernels
+// ... and Pleiades' own entry points (d = 28)
 int launch_filter_pleiades(int q, int ek1, const TeamFilterParams& TP, hipStream_t s);        // global-workspace team kernel
 int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive = 0, double* stage = nullptr,
                                  size_t stage_doubles = 0);  // register-tiled kernel (default)
@@ -40,5 +54,4 @@ int launch_dense_d28(int q, const DenseParams& P, double* ws, hipStream_t s);  /
 long dense_d28_grid(long items);
 int launch_sample_d28(int q, const SampleParams& P, double* ws, hipStream_t s);  // ws: dense_d28_grid(N n_samples) x team_smooth_ws_doubles
 size_t team_filter_ws_doubles(int d, int q);
-size_t team_smooth_ws_doubles(int d, int q);
 }  // namespace odef

@@ -315,6 +315,29 @@ struct RhsLinear {  // test/convergence.jl:9-14, test/state_init.jl:12-17
 };
 
 
+// Lorenz-96 with 16 variables, u_i' = (u_{i+1} - u_{i-2}) u_{i-1} - u_i + F, p = (F): the second vector field of the
+// workgroup-per-trajectory kernels (state dimension 16 (q+1): 64 at order 3, 96 at order 5).  It has none of Pleiades' team
+// evaluation hooks: the kernels' generic path evaluates f and the Jacobian in one lane.
+struct RhsLorenz96 {
+  static constexpr int d = 16, np = 1, id = 6;
+  static constexpr const char* name = "RhsLorenz96";
+  template <class T>
+  __device__ static void f(const T (&u)[16], const double* p, T (&du)[16]) {
+    for (int i = 0; i < 16; ++i) du[i] = (u[(i + 1) % 16] - u[(i + 14) % 16]) * u[(i + 15) % 16] - u[i] + p[0];
+  }
+  __device__ static void jac(const double (&u)[16], const double* /*p*/, double (&J)[16][16]) {
+    for (int a = 0; a < 16; ++a)
+      for (int b = 0; b < 16; ++b) J[a][b] = 0.0;
+    for (int i = 0; i < 16; ++i) {
+      const int ip = (i + 1) % 16, im2 = (i + 14) % 16, im1 = (i + 15) % 16;
+      J[i][ip] += u[im1];
+      J[i][im2] -= u[im1];
+      J[i][im1] += u[ip] - u[im2];
+      J[i][i] -= 1.0;
+    }
+  }
+};
+
 // Pleiades 7-body problem (Hairer et al. IVP test set): state (x1..7, y1..7, x'1..7, y'1..7), masses m_i = i,
 //   x_i'' = sum_{j != i} m_j (x_j - x_i) / r_ij^3.   BASELINE.json config 4 (d = 28, D = 168 at order 5).
 struct RhsPleiades {

@@ -1,0 +1,139 @@
+// Host-side launch paths of the workgroup-per-trajectory kernels (matrix-core filter / smoother / dense output / sampler,
+// record stage), written once for any vector field with an even d <= 32 and instantiated per field (inst_pleiades.hip: d = 28,
+// with the VALU kernels of round 1 as alternates; inst_lorenz96.hip: d = 16, matrix cores only).
+#pragma once
+#include "ek_kernels.h"
+
+namespace odef {
+
+// grid.z of the staging kernels counts records: at most 65 535 per launch
+inline void launch_stage_copy(bool in, const double* src, double* dst, long N, long TRI, long ld, long n_rec, hipStream_t s) {
+  const dim3 tiles((unsigned)((N + kStageTile - 1) / kStageTile), (unsigned)((TRI + kStageTile - 1) / kStageTile));
+  for (long r0 = 0; r0 < n_rec; r0 += 65535) {
+    const unsigned nz = (unsigned)(n_rec - r0 < 65535 ? n_rec - r0 : 65535);
+    const size_t so = (size_t)r0 * (size_t)N * (size_t)(in ? TRI : ld), dof = (size_t)r0 * (size_t)N * (size_t)(in ? ld : TRI);
+    if (in)
+      hipLaunchKernelGGL(stage_in_kernel<kStageTile>, dim3(tiles.x, tiles.y, nz), dim3(256), 0, s, src + so, dst + dof, N, TRI, ld);
+    else
+      hipLaunchKernelGGL(stage_out_kernel<kStageTile>, dim3(tiles.x, tiles.y, nz), dim3(256), 0, s, src + so, dst + dof, N, TRI, ld);
+  }
+}
+
+// Fixed grid on the matrix-core kernel with every step saved: when `stage` holds all nsteps + 1 records the kernel writes
+// its covariance records there (trajectory-major, whole lines) and one transposition pass moves them to P.cov.
+// `by_order(q, ek1, P, s, adaptive)`: the field's filter launcher for one order.
+template <int d, class ByOrder>
+int team_filter_staged(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles,
+                       bool valu_kernel_selected, ByOrder&& by_order) {
+  const long D = (long)d * (q + 1), TRI = D * (D + 1) / 2, ld = stage_record_ld(TRI), n_rec = P.nsteps + 1;
+  if (adaptive || !P.everystep || valu_kernel_selected || !stage || (size_t)n_rec * (size_t)P.N * (size_t)ld > stage_doubles)
+    return by_order(q, ek1, P, s, adaptive);
+  FilterParams PS = P;
+  PS.cov_stage = stage;
+  PS.stage_ld = ld;
+  const int rc = by_order(q, ek1, PS, s, 0);
+  if (rc) return rc;
+  launch_stage_copy(false, stage, P.cov, P.N, TRI, ld, n_rec, s);
+  return 0;
+}
+
+// The smoother pass with the covariance records staged trajectory-major (record_stage.h), in blocks of as many records as
+// `stage` holds, from the last record down: [records in] -> smoother launch over the block (carried state in the workspace)
+// -> [records out].  `n_rec`: number of save slots in use (fixed grids: n_save; adaptive: the largest nsaved of the
+// ensemble -- every trajectory joins in at the block that holds its own last record).  stage_doubles must hold at
+// least two records.
+template <int d, bool VALU_ALTERNATES>
+int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s) {
+  const long n = n_rec, N = P0.N;
+  const long D = (long)d * (q + 1), TRI = D * (D + 1) / 2, ld = stage_record_ld(TRI);
+  const size_t per_rec = (size_t)N * (size_t)ld;
+  const long cap = (long)(stage_doubles / per_rec);
+  if (n < 2 || n > P0.n_save || cap < 2 || (VALU_ALTERNATES && pleiades_smooth_team())) return -4;  // the caller runs the pass on the records in place
+  // record 0 is never smoothed (src/smoothing.jl:11) and never staged: copied here (a trajectory that has no other record
+  // is not visited by any launch)
+  if (hipMemcpyAsync(P0.scov, P0.cov, (size_t)TRI * (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return -5;
+  if (hipMemcpyAsync(P0.smean, P0.mean, (size_t)D * (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return -5;
+  long top = n - 1;  // highest record not yet through the stage
+  while (top >= 1) {
+    const long hi = top, lo = hi - cap + 1 > 1 ? hi - cap + 1 : 1;
+    SmoothParams P = P0;
+    P.stage = stage;
+    P.stage_s0 = lo;
+    P.stage_hi = hi;
+    P.stage_ld = ld;
+    launch_stage_copy(true, P0.cov + (size_t)lo * TRI * N, stage, N, TRI, ld, hi - lo + 1, s);
+    if (!pleiades_smooth_split()) {
+      LaunchTeamSmoothT<VALU_ALTERNATES> f{P, ws, s};
+      const int rc = dispatch_smooth_order<d>(q, f);
+      if (rc) return rc;
+    } else {
+      // one kernel per phase and record: [set up the block] then, record by record from the top,
+      // [finish record r + 1 | begin record r] -> [sweeps of record r with the factor in LDS]; trajectories that do not have
+      // the record (adaptive solves) or repeat a save time skip their part inside the kernels
+      P.split_mode = 1;
+      P.split_sc = P.split_sa = -1;
+      {
+        LaunchTeamSmoothT<VALU_ALTERNATES> f{P, ws, s};
+        const int rc = dispatch_smooth_order<d>(q, f);
+        if (rc) return rc;
+      }
+      const long r_hi = hi < n - 2 ? hi : n - 2, r_lo = lo;
+      P.split_mode = 2;
+      for (long r = r_hi; r >= r_lo - 1; --r) {
+        P.split_sc = r + 1 <= r_hi ? r + 1 : -1;
+        P.split_sa = r >= r_lo ? r : -1;
+        {
+          LaunchTeamSmoothT<VALU_ALTERNATES> f{P, ws, s};
+          const int rc = dispatch_smooth_order<d>(q, f);
+          if (rc) return rc;
+        }
+        if (P.split_sa >= 0) {
+          LaunchTeamSmoothSweeps g{P, ws, s};
+          const int rc = dispatch_smooth_order<d>(q, g);
+          if (rc || g.rc) return rc ? rc : g.rc;
+        }
+      }
+    }
+    launch_stage_copy(false, stage, P0.scov + (size_t)lo * TRI * N, N, TRI, ld, hi - lo + 1, s);
+    top = lo - 1;
+  }
+  return 0;
+}
+
+template <int d, bool VALU_ALTERNATES>
+int team_smooth_inplace(int q, const SmoothParams& P, double* ws, hipStream_t s) {
+  LaunchTeamSmoothT<VALU_ALTERNATES> f{P, ws, s};
+  return dispatch_smooth_order<d>(q, f);
+}
+template <int d>
+int team_dense(int q, const DenseParams& P, double* ws, hipStream_t s) {
+  LaunchTeamDense f{P, ws, s};
+  return dispatch_smooth_order<d>(q, f);
+}
+template <int d>
+int team_sample(int q, const SampleParams& P, double* ws, hipStream_t s) {
+  LaunchTeamSample f{P, ws, s};
+  return dispatch_smooth_order<d>(q, f);
+}
+template <int d, bool VALU_ALTERNATES>
+size_t team_smooth_ws(int q) {
+  auto one = [](auto nbc) -> size_t {
+    constexpr int NB = decltype(nbc)::value;
+    size_t a = MfmaSmoothWs<d, NB>::size;
+    if constexpr (VALU_ALTERNATES) {  // the larger of the two smoothers' workspaces (smooth_team.h: 3 D x D matrices; smooth_mfma.h: 7 padded ones)
+      const size_t b = (size_t)SmoothWs<d, NB>::size;
+      a = a > b ? a : b;
+    }
+    return a;
+  };
+  switch (q) {
+    case 1: return one(std::integral_constant<int, 2>{});
+    case 2: return one(std::integral_constant<int, 3>{});
+    case 3: return one(std::integral_constant<int, 4>{});
+    case 4: return one(std::integral_constant<int, 5>{});
+    case 5: return one(std::integral_constant<int, 6>{});
+    default: return 0;
+  }
+}
+
+}  // namespace odef

@@ -25,9 +25,9 @@ LIB_PATH = os.environ.get("ODEFILTER_HIP_LIB") or os.path.join(_HERE, "lib", "li
 # ---- enums (include/odefilter.h) ---------------------------------------------------------
 EK0_ID, EK1_ID = 0, 1
 DIFFUSION = {"dynamic": 0, "fixed": 1, "fixedMAP": 2}
-RHS = {"fhn": 0, "lorenz63": 1, "lotka_volterra": 2, "vanderpol": 3, "linear": 4, "pleiades": 5}
+RHS = {"fhn": 0, "lorenz63": 1, "lotka_volterra": 2, "vanderpol": 3, "linear": 4, "pleiades": 5, "lorenz96": 6}
 RHS_DIMS = {"fhn": (2, 3), "lorenz63": (3, 3), "lotka_volterra": (2, 4), "vanderpol": (2, 1), "linear": (2, 2),
-            "pleiades": (28, 0)}
+            "pleiades": (28, 0), "lorenz96": (16, 1)}
 SAVE_FINAL, SAVE_EVERYSTEP = 0, 1
 RETCODES = {0: "Success", 1: "MaxIters", 2: "DtLessThanMin", 3: "Unstable", 4: "Unstable"}
 (F_MEAN, F_COV_TRIL, F_DIFFUSION, F_T, F_LOGLIK, F_NACCEPT, F_NREJECT, F_NF, F_NJAC, F_NSAVED, F_RETCODE,

@@ -413,7 +413,24 @@ def _pleiades_jac(u, p, t):
     return J
 
 
-RHS_FHN, RHS_LORENZ63, RHS_LOTKA_VOLTERRA, RHS_VANDERPOL, RHS_LINEAR, RHS_PLEIADES = 0, 1, 2, 3, 4, 5
+def _l96_f(u, p, t):
+    n = len(u)
+    return [(u[(i + 1) % n] - u[(i - 2) % n]) * u[(i - 1) % n] - u[i] + p[0] for i in range(n)]
+
+
+def _l96_jac(u, p, t):
+    n = len(u)
+    J = np.zeros((n, n))
+    for i in range(n):
+        ip, im2, im1 = (i + 1) % n, (i - 2) % n, (i - 1) % n
+        J[i, ip] += u[im1]
+        J[i, im2] -= u[im1]
+        J[i, im1] += u[ip] - u[im2]
+        J[i, i] -= 1.0
+    return J
+
+
+RHS_FHN, RHS_LORENZ63, RHS_LOTKA_VOLTERRA, RHS_VANDERPOL, RHS_LINEAR, RHS_PLEIADES, RHS_LORENZ96 = 0, 1, 2, 3, 4, 5, 6
 
 
 def vector_field(name: str) -> VectorField:
@@ -433,6 +450,10 @@ def vector_field(name: str) -> VectorField:
             + [0.0, 0.0, 0.0, 0.0, 0.0, 1.75, -1.5, 0.0, 0.0, 0.0, -1.25, 1.0, 0.0, 0.0]
         )
         return VectorField("pleiades", RHS_PLEIADES, 28, 0, _pleiades_f, _pleiades_jac, u0, np.zeros(0), (0.0, 0.25))
+    if name == "lorenz96":  # 16 variables: a second shape for the workgroup-per-trajectory kernels (no counterpart in the reference's tests)
+        u0 = 8.0 + np.array([0.01 * ((7 * i) % 5 - 2) for i in range(16)])
+        u0[0] += 1.0
+        return VectorField("lorenz96", RHS_LORENZ96, 16, 1, _l96_f, _l96_jac, u0, np.array([8.0]), (0.0, 0.25))
     raise KeyError(name)
 
 

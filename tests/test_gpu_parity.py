@@ -412,6 +412,65 @@ def test_pleiades_ensemble_parity(pkg, q, kind, tag, kernels, monkeypatch):
             assert w.min() >= -1e-9 * np.abs(w).max()
 
 
+# ---- the workgroup-per-trajectory kernels on a second shape: Lorenz-96, d = 16 (csrc/inst_lorenz96.hip) ----
+
+
+@pytest.mark.parametrize("smoother", ["split", "persistent"])
+@pytest.mark.parametrize("q,kind", [(2, "EK1"), (3, "EK1"), (3, "EK0"), (5, "EK1")])
+def test_lorenz96_on_the_matrix_core_kernels(pkg, q, kind, smoother, monkeypatch):
+    """filter_mfma.h / smooth_mfma.h are templates over the vector field; until round 3 only Pleiades (d = 28) instantiated
+    them.  Lorenz-96 with 16 variables runs the same kernels with derivative blocks of two 8-row tiles (state dimension 48,
+    64, 96) and WITHOUT the team-evaluation hooks Pleiades provides (f and the Jacobian come from the generic one-lane path):
+    filter and smoother against the oracle, means of the solution at 1e-10, the higher blocks and the covariances at the
+    oracle's own rounding-noise level, positive semi-definite covariances."""
+    monkeypatch.setenv("ODEF_SMOOTH_SPLIT", "1" if smoother == "split" else "0")
+    vf = orc.vector_field("lorenz96")
+    N, ns, dt = 6, 12, 2.0**-7
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz96", vf.u0, (0.0, ns * dt), vf.p), perturb_scale=1e-2)
+    sol = pkg.solve(ens, _alg(pkg, kind, q), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
+    assert sol.retcode == ["Success"] * N
+    assert "ek_filter_mfma_kernel<odef::RhsLorenz96" in sol.ctx.kernel_name(0) and "rts_smooth_mfma_kernel<16" in sol.ctx.kernel_name(1)
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    np.testing.assert_array_equal(sol.ctx.get(13).T, u0s)
+    alg_o = orc.Alg(kind, q, "dynamic", True)
+    mf, ms, cf, cs = sol.x_filt_mean(), sol.x_smooth_mean(), sol.x_filt_cov(), sol.x_smooth_cov()
+    for i in (0, 5):
+        for smoothed, m, c in ((False, mf, cf), (True, ms, cs)):
+            base, nm, nc = P.oracle_noise(vf, alg_o, u0s[i], dict(tspan=(0.0, ns * dt), dt=dt), smoothed)
+            P.check_against_oracle(m[i], c[i], base.means(smoothed=smoothed), base.covs(smoothed=smoothed), 16, nm, nc,
+                                   f"lorenz96 {kind}({q}) {smoother} traj {i} smoothed={smoothed}")
+        for c in (cf[i][-1], cs[i][1]):
+            w = np.linalg.eigvalsh(c)
+            assert w.min() >= -1e-9 * np.abs(w).max()
+    np.testing.assert_allclose(sol.log_likelihood[0], orc.solve(vf, alg_o, u0=u0s[0], tspan=(0.0, ns * dt), dt=dt).log_likelihood, rtol=1e-6)
+
+
+def test_lorenz96_adaptive_dense_output_and_sampling(pkg):
+    """... and the rest of the path on that shape: the adaptive matrix-core filter (PI controller, one record per attempt)
+    against the oracle's OrdinaryDiffEq loop, the smoother over its records, sol(t) (csrc/dense_mfma.h) and posterior
+    sampling (csrc/sample_mfma.h) at D = 64."""
+    vf = orc.vector_field("lorenz96")
+    N, t1 = 3, 0.1
+    ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz96", vf.u0, (0.0, t1), vf.p), perturb_scale=1e-2)
+    sol = pkg.solve(ens, pkg.EK1(order=3), pkg.EnsembleHIP(), trajectories=N, dt=2.0**-8, adaptive=True, abstol=1e-8, reltol=1e-6, max_steps=256)
+    assert sol.retcode == ["Success"] * N
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    consts = orc.make_consts(16, 3)
+    for i in (0, 2):
+        ref = orc.solve(vf, orc.EK1(order=3), u0=u0s[i], tspan=(0.0, t1), dt=2.0**-8, adaptive=True, abstol=1e-8, reltol=1e-6)
+        n = len(ref.t)
+        assert int(sol.nsaved[i]) == n and int(sol.destats.nreject[i]) == ref.nreject
+        np.testing.assert_allclose(sol.t[i][:n], ref.t, rtol=1e-6)
+        np.testing.assert_allclose(sol.u[i][:n], ref.u, rtol=1e-6, atol=1e-9)
+        tq = np.array([0.011, 0.05, t1])
+        qm, qc = sol(tq)
+        want = np.array([orc.dense_output(ref, consts, float(t)).mu[:16] for t in tq])
+        np.testing.assert_allclose(qm[i][:, :16], want, rtol=1e-6, atol=1e-9)
+    smp = sol.sample_states(2, 11, noise_scale=0.0)  # the chain of conditional means = the smoothed means
+    n0 = int(sol.nsaved[0])
+    np.testing.assert_allclose(smp[0][:n0, :16, 0], sol.x_smooth_mean()[0][:n0, :16], rtol=1e-7, atol=1e-10)
+
+
 @pytest.mark.parametrize("q", [1, 3, 5])
 def test_pleiades_mfma_kernel_against_tiles_kernel_nonuniform_grid(pkg, q, monkeypatch):
     """The two D = 28 (q+1) fixed-step filters -- matrix cores / Joseph form (csrc/filter_mfma.h, default) and register tiles /
