@@ -287,24 +287,50 @@ __device__ __attribute__((always_inline)) inline void pin(double (&a)[n]) {
 #endif
 }
 
-// two_sided_inverse with the factor in the AGPR file (slots LS + tri(i, k); the DIAGONAL slots hold 1 / L_kk, which is all
-// the transforms need of the diagonal): column k of L is fetched once per pivot and pass
-template <int D, int LS, bool MINUS_IDENTITY>
+// In-place B = L D L' of a packed symmetric matrix: unit lower L below the diagonal (the diagonal entries are left as the pivots
+// D_k), dinv[k] = 1 / D_k.  A non-positive pivot zeroes its column and gets the reciprocal 0 -- the rule of chol_packed
+// (ek_math.h), i.e. the factor the reference's QR fallback yields for a positive semi-definite matrix (src/filtering.jl:38-47).
+// No square roots: 12 pivots x (v_rcp_f64 + two Newton steps) instead of 12 x the 14-instruction sqrt / rsqrt sequence.
+template <int D>
+__device__ inline void ldl_packed_lane(double (&B)[D * (D + 1) / 2], double (&dinv)[D]) {
+  static_for<0, D>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const double piv = B[tri(k, k)];
+    const bool ok = piv > 0.0;
+    const double inv = ok ? rcp_pos(ok ? piv : 1.0) : 0.0;
+    dinv[k] = inv;
+    double v[D];
+#pragma unroll
+    for (int i = k + 1; i < D; ++i) {
+      v[i] = B[tri(i, k)];
+      B[tri(i, k)] = v[i] * inv;
+    }
+#pragma unroll
+    for (int j = k + 1; j < D; ++j)
+#pragma unroll
+      for (int i = j; i < D; ++i) B[tri(i, j)] = __builtin_fma(-B[tri(i, k)], v[j], B[tri(i, j)]);
+  });
+}
+
+// S <- B^-1 (S - B) B^-1 for B = L D L' with the factor in the AGPR file (slots LS + tri(i, k) hold the unit lower L, the DIAGONAL
+// slots 1 / D_k): column k of L is fetched once per pivot and pass.
+//   forward, unit lower:      S <- L^-1 S L^-T         (no scaling: the elementary congruences of a unit factor)
+//   middle:                   S <- D^-1 S D^-1 - D^-1   = D^-1 (L^-1 (S - B) L^-T) D^-1, since L^-1 B L^-T = D: the difference
+//                             S^s_+ - S^- the smoother needs is taken HERE, on the whitened matrix, so that it never has to be
+//                             formed (and parked) before the factorisation overwrites S^-.  A zeroed column (1 / D_k taken as 0)
+//                             zeroes its row and column and subtracts nothing.
+//   backward, unit upper:     S <- L^-T S L^-1
+template <int D, int LS>
 __device__ inline void two_sided_inverse_parked(double (&S)[D * (D + 1) / 2]) {
   static_for<0, D>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    const double inv = aget<LS + tri(k, k)>();
     double lc[D];
     static_for<k + 1, D>([&](auto ic) { lc[decltype(ic)::value] = aget<LS + tri(decltype(ic)::value, k)>(); });
-    const double tkk = S[tri(k, k)] * inv * inv;
-    S[tri(k, k)] = tkk;
-    const double htkk = -0.5 * tkk;
-#pragma unroll
-    for (int j = 0; j < k; ++j) S[tri(k, j)] *= inv;
+    const double htkk = -0.5 * S[tri(k, k)];
     double b[D];
 #pragma unroll
     for (int i = k + 1; i < D; ++i) {
-      b[i] = __builtin_fma(lc[i], htkk, S[tri(i, k)] * inv);
+      b[i] = __builtin_fma(lc[i], htkk, S[tri(i, k)]);
 #pragma unroll
       for (int j = 0; j < k; ++j) S[tri(i, j)] = __builtin_fma(-lc[i], S[tri(k, j)], S[tri(i, j)]);
     }
@@ -317,18 +343,20 @@ __device__ inline void two_sided_inverse_parked(double (&S)[D * (D + 1) / 2]) {
     pin(S);
     ODEF_SCHED_FENCE();
   });
-  if constexpr (MINUS_IDENTITY) {
-    // L^-1 (S - B) L^-T = L^-1 S L^-T - I: the difference S^s_+ - S^- the smoother needs is taken HERE, on the whitened
-    // matrix, so that S^s_+ - S^- never has to be formed (and parked) before the factorisation overwrites S^-.  A zeroed
-    // column of the factor (semi-definite S^-) has L^-1 taken as 0 there: its diagonal entry stays 0.
-    static_for<0, D>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      S[tri(k, k)] -= (aget<LS + tri(k, k)>() != 0.0) ? 1.0 : 0.0;
-    });
+  {
+    double di[D];
+    static_for<0, D>([&](auto kc) { di[decltype(kc)::value] = aget<LS + tri(decltype(kc)::value, decltype(kc)::value)>(); });
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+      for (int j = 0; j < i; ++j) S[tri(i, j)] = (S[tri(i, j)] * di[i]) * di[j];
+      S[tri(i, i)] = __builtin_fma(S[tri(i, i)] * di[i], di[i], -di[i]);
+    }
+    pin(S);
+    ODEF_SCHED_FENCE();
   }
   static_for<0, D>([&](auto kc) {
     constexpr int k = D - 1 - decltype(kc)::value;
-    const double inv = aget<LS + tri(k, k)>();
     double lc[D];
     static_for<k + 1, D>([&](auto ic) { lc[decltype(ic)::value] = aget<LS + tri(decltype(ic)::value, k)>(); });
     double t[D];
@@ -344,8 +372,8 @@ __device__ inline void two_sided_inverse_parked(double (&S)[D * (D + 1) / 2]) {
     for (int i = k + 1; i < D; ++i) tk -= lc[i] * t[i];
 #pragma unroll
     for (int j = 0; j < D; ++j)
-      if (j != k) S[symidx(k, j)] = t[j] * inv;
-    S[tri(k, k)] = tk * inv * inv;
+      if (j != k) S[symidx(k, j)] = t[j];
+    S[tri(k, k)] = tk;
     pin(S);
     ODEF_SCHED_FENCE();
   });
@@ -459,26 +487,27 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
     predict_cov_inplace<d, NB>(pc, B, sigma2);  // src/smoothing.jl:38
     pin(B);
     ODEF_SCHED_FENCE();
-    int fixes = 0;
-    double dinv[D];  // 1 / L_kk (0 for a zeroed column): every later division by a pivot is a multiplication with these
-    chol_packed<D>(B, fixes, dinv);
+    double dinv[D];  // 1 / D_k of S^- = L D L' (0 for a zeroed column)
+    ldl_packed_lane<D>(B, dinv);
     pin(B);
     pin(dinv);
     ODEF_SCHED_FENCE();
-    // w = A' B^-1 delta ;  m^s = m + X w  (src/smoothing.jl:42-44)
+    // w = A' B^-1 delta ;  m^s = m + X w  (src/smoothing.jl:42-44): unit-lower forward, D^-1, unit-upper backward
 #pragma unroll
     for (int k = 0; k < D; ++k) {
       double t = dl[k];
 #pragma unroll
       for (int c = 0; c < k; ++c) t -= B[tri(k, c)] * dl[c];
-      dl[k] = t * dinv[k];
+      dl[k] = t;
     }
+#pragma unroll
+    for (int k = 0; k < D; ++k) dl[k] *= dinv[k];
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
       double t = dl[k];
 #pragma unroll
       for (int c = k + 1; c < D; ++c) t -= B[tri(c, k)] * dl[c];
-      dl[k] = t * dinv[k];
+      dl[k] = t;
     }
 #pragma unroll
     for (int K = NB - 1; K >= 1; --K)  // w = A' (.) in place: block K takes the still-untouched blocks j < K
@@ -510,13 +539,13 @@ __device__ inline void smooth_lane_v2(const SmoothParams& P, long i0, unsigned l
       constexpr int a = [] { int r = 0; while ((r + 1) * (r + 2) / 2 <= k) ++r; return r; }();
       constexpr int b = k - a * (a + 1) / 2;
       S[k] = aget<MS + k>();
-      aput<MS + k>(a == b ? dinv[a] : B[k]);  // (the diagonal slot takes 1 / L_kk)
+      aput<MS + k>(a == b ? dinv[a] : B[k]);  // (the diagonal slot takes 1 / D_k)
       S[k] *= pj[a / d] * pj[b / d];
     });
     pin(S);
     ODEF_SCHED_FENCE();
     // Z = B^-1 (S^s_+ - B) B^-1 ;  W = A' Z A
-    two_sided_inverse_parked<D, MS, true>(S);
+    two_sided_inverse_parked<D, MS>(S);
     pin(S);
     ODEF_SCHED_FENCE();
     congruence_At_inplace<d, NB>(pc, S);
