@@ -593,22 +593,14 @@ int odef_solve_fixed(odef_ctx* c, const double* tgrid, int64_t n_t) {
   P.t0 = c->t0;
   int rc;
   if (c->team_path) {
-    const char* path = getenv("ODEF_PLEIADES_PATH");  // "team": the global-workspace kernel, for A/B comparison (Pleiades only)
-    if (c->cfg.rhs_id == ODEF_RHS_PLEIADES && path && std::strcmp(path, "team") == 0) {
-      if (ensure_ws(c, (size_t)c->cfg.n_traj * team_filter_ws_doubles(c->d, c->q))) return -1;
-      TeamFilterParams TP{P, c->d_ws};
-      HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-      rc = launch_filter_pleiades(c->q, c->cfg.alg == ODEF_EK1, TP, c->stream);
-    } else {
-      size_t have = 0;
-      if (P.everystep) {  // the matrix-core kernel writes its records through the trajectory-major stage when all of them fit
-        const size_t tri = (size_t)c->D * (c->D + 1) / 2, per_rec = (size_t)P.N * ((tri + 15) / 16 * 16);
-        have = ensure_stage(c, nsteps + 1, per_rec);
-        if (have < (size_t)(nsteps + 1) * per_rec) have = 0;
-      }
-      HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-      rc = c->team->filter(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 0, have ? c->d_stage : nullptr, have);
+    size_t have = 0;
+    if (P.everystep) {  // the matrix-core kernel writes its records through the trajectory-major stage when all of them fit
+      const size_t tri = (size_t)c->D * (c->D + 1) / 2, per_rec = (size_t)P.N * ((tri + 15) / 16 * 16);
+      have = ensure_stage(c, nsteps + 1, per_rec);
+      if (have < (size_t)(nsteps + 1) * per_rec) have = 0;
     }
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    rc = c->team->filter(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 0, have ? c->d_stage : nullptr, have);
   } else {
     // one lane per trajectory: the per-field buffer descriptors carry 32-bit sizes
     if ((size_t)c->TRI * (size_t)c->cfg.n_traj * sizeof(double) >= (1ull << 31))

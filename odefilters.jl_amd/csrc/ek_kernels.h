@@ -5,12 +5,10 @@
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include "dispatch.h"
-#include "smooth_team.h"
 #include "smooth_rows.h"
 #include "smooth_lane.h"
 #include "dense_lane.h"
 #include "sample_lane.h"
-#include "filter_team.h"
 #include "filter_tiles.h"
 #include "record_stage.h"
 #include "filter_mfma.h"
@@ -172,21 +170,7 @@ struct LaunchSample {
   }
 };
 
-// Workgroup-per-trajectory kernels (large state dimension): 256 threads cooperate on one trajectory,
-// matrices in a per-trajectory global workspace.
-constexpr int kTeamBig = 256;
-template <class RHS, int q, bool EK1>
-__global__ __launch_bounds__(kTeamBig) void ek_filter_team_kernel(const TeamFilterParams TP) {
-  using TF = TeamFilter<RHS, q, EK1, kTeamBig>;
-  __shared__ double sm[TF::W::small_size];
-  TF::run(TP, (long)blockIdx.x, (int)threadIdx.x, sm);
-}
-template <int d, int q>
-__global__ __launch_bounds__(kTeamBig) void rts_smooth_team_kernel(const SmoothParams P, double* ws) {
-  const long i = team_traj(P.N);
-  if (i < 0) return;
-  smooth_team_lane<d, q, kTeamBig>(P, i, (int)threadIdx.x, ws + (size_t)i * SmoothWs<d, q + 1>::size);
-}
+constexpr int kTeamBig = 256;  // threads of the workgroup-per-trajectory smoother / dense output / sampler kernels
 
 // Register-tiled workgroup-per-trajectory filter (filter_tiles.h): 320 threads with one 7 x 7 covariance tile each
 // plus one helper wavefront for the small sequential factorisations.
@@ -248,15 +232,6 @@ struct LaunchTilesFilterT {
 };
 using LaunchTilesFilter = LaunchTilesFilterT<true>;
 
-struct LaunchTeamFilter {
-  const TeamFilterParams& TP;
-  hipStream_t s;
-  template <class RHS, int q, bool EK1>
-  void operator()() {
-    note_kernel("odef::ek_filter_team_kernel<odef::%s, %d, %s>", RHS::name, q, tf(EK1));
-    hipLaunchKernelGGL((ek_filter_team_kernel<RHS, q, EK1>), dim3((unsigned)TP.fp.N), dim3(kTeamBig), 0, s, TP);
-  }
-};
 // The same pass on the matrix cores (smooth_mfma.h): 4 wavefronts per trajectory, matrices in a global workspace.
 // Four workgroups per CU (128 registers): the phases are bound by the latency and traffic of the global workspace, and more
 // resident workgroups hide more of it -- 319 / 307 / 273 ms with 2 / 3 / 4 (2 048 trajectories x 64 steps).
@@ -391,10 +366,6 @@ inline bool pleiades_smooth_split() {  // the staged pass as a sequence of kerne
   const char* e = getenv("ODEF_SMOOTH_SPLIT");
   return !(e && e[0] == '0');
 }
-inline bool pleiades_smooth_team() {  // ODEF_PLEIADES_SMOOTH=team: the first (vector-FMA) D = 168 smoother, for A/B comparison
-  const char* e = getenv("ODEF_PLEIADES_SMOOTH");
-  return e && e[0] == 't';
-}
 #ifndef ODEF_HOST_EMUL
 // Dense output for the workgroup-per-trajectory path (dense_mfma.h): items = (trajectory, query time), grid-strided over
 // gridDim.x workspaces of the MFMA smoother's size
@@ -467,29 +438,20 @@ struct LaunchTeamSmoothSweeps {
     hipLaunchKernelGGL((rts_smooth_sweeps_kernel<d, q>), dim3(team_grid(P.N)), dim3(64 * W::DPB), lds_bytes, s, P, ws);
   }
 };
-template <bool VALU_ALTERNATES = true>
-struct LaunchTeamSmoothT {
+struct LaunchTeamSmooth {
   const SmoothParams& P;
   double* ws;
   hipStream_t s;
   template <int d, int q>
   void operator()() {
     // (the workspace kernel of the pass: the dominant one also when the sweeps run in a kernel of their own)
-    const bool team = VALU_ALTERNATES && pleiades_smooth_team();
-    note_kernel(team ? "odef::rts_smooth_team_kernel<%d, %d>" : P.split_mode != 0 ? "odef::rts_smooth_mfma_kernel<%d, %d, true>" : "odef::rts_smooth_mfma_kernel<%d, %d, false>", d, q);
-    if constexpr (VALU_ALTERNATES) {
-      if (team) {
-        hipLaunchKernelGGL((rts_smooth_team_kernel<d, q>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
-        return;
-      }
-    }
+    note_kernel(P.split_mode != 0 ? "odef::rts_smooth_mfma_kernel<%d, %d, true>" : "odef::rts_smooth_mfma_kernel<%d, %d, false>", d, q);
     if (P.split_mode != 0)
       hipLaunchKernelGGL((rts_smooth_mfma_kernel<d, q, true>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
     else
       hipLaunchKernelGGL((rts_smooth_mfma_kernel<d, q, false>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
   }
 };
-using LaunchTeamSmooth = LaunchTeamSmoothT<true>;
 
 struct LaunchFilter {
   const FilterParams& P;

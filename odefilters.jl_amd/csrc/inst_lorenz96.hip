@@ -10,13 +10,13 @@ static int filter_l96_order(int q, int ek1, const FilterParams& P, hipStream_t s
 static int filter_l96(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles) {
   return team_filter_staged<16>(q, ek1, P, s, adaptive, stage, stage_doubles, false, filter_l96_order);
 }
-static int smooth_l96(int q, const SmoothParams& P, double* ws, hipStream_t s) { return team_smooth_inplace<16, false>(q, P, ws, s); }
+static int smooth_l96(int q, const SmoothParams& P, double* ws, hipStream_t s) { return team_smooth_inplace<16>(q, P, ws, s); }
 static int smooth_l96_staged(int q, const SmoothParams& P, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s) {
-  return team_smooth_staged<16, false>(q, P, n_rec, ws, stage, stage_doubles, s);
+  return team_smooth_staged<16>(q, P, n_rec, ws, stage, stage_doubles, s);
 }
 static int dense_l96(int q, const DenseParams& P, double* ws, hipStream_t s) { return team_dense<16>(q, P, ws, s); }
 static int sample_l96(int q, const SampleParams& P, double* ws, hipStream_t s) { return team_sample<16>(q, P, ws, s); }
-static size_t smooth_ws_l96(int q) { return team_smooth_ws<16, false>(q); }
+static size_t smooth_ws_l96(int q) { return team_smooth_ws<16>(q); }
 const TeamLaunch* team_lorenz96() {
   static const TeamLaunch t = {16, filter_l96, smooth_l96, smooth_l96_staged, dense_l96, sample_l96, smooth_ws_l96};
   return &t;

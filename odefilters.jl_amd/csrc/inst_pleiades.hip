@@ -1,9 +1,5 @@
 #include "team_launch_impl.h"
 namespace odef {
-int launch_filter_pleiades(int q, int ek1, const TeamFilterParams& TP, hipStream_t s) {
-  LaunchTeamFilter f{TP, s};
-  return dispatch_order<RhsPleiades>(q, ek1, f);
-}
 // the tiled filter is instantiated one order per translation unit (inst_pleiades_tiles.hip with -DODEF_TILES_Q=q):
 // its kernels are the longest compiles of the library and used to serialise the build behind this file
 int launch_filter_pleiades_tiles_q1(int ek1, const FilterParams& P, hipStream_t s, int adaptive);
@@ -24,25 +20,14 @@ static int launch_filter_pleiades_tiles_order(int q, int ek1, const FilterParams
 int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles) {
   return team_filter_staged<28>(q, ek1, P, s, adaptive, stage, stage_doubles, pleiades_filter_tiles(), launch_filter_pleiades_tiles_order);
 }
-int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s) { return team_smooth_inplace<28, true>(q, P, ws, s); }
+int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s) { return team_smooth_inplace<28>(q, P, ws, s); }
 int launch_smooth_d28_staged(int q, const SmoothParams& P0, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s) {
-  return team_smooth_staged<28, true>(q, P0, n_rec, ws, stage, stage_doubles, s);
+  return team_smooth_staged<28>(q, P0, n_rec, ws, stage, stage_doubles, s);
 }
 int launch_dense_d28(int q, const DenseParams& P, double* ws, hipStream_t s) { return team_dense<28>(q, P, ws, s); }
 int launch_sample_d28(int q, const SampleParams& P, double* ws, hipStream_t s) { return team_sample<28>(q, P, ws, s); }
 long dense_d28_grid(long items) { return items < kDenseMfmaMaxGrid ? items : kDenseMfmaMaxGrid; }
-size_t team_filter_ws_doubles(int d, int q) {
-  if (d != 28) return 0;
-  switch (q) {
-    case 1: return FilterWs<28, 2>::size;
-    case 2: return FilterWs<28, 3>::size;
-    case 3: return FilterWs<28, 4>::size;
-    case 4: return FilterWs<28, 5>::size;
-    case 5: return FilterWs<28, 6>::size;
-    default: return 0;
-  }
-}
-static size_t smooth_ws_pleiades(int q) { return team_smooth_ws<28, true>(q); }
+static size_t smooth_ws_pleiades(int q) { return team_smooth_ws<28>(q); }
 static int filter_pleiades(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles) {
   return launch_filter_pleiades_tiles(q, ek1, P, s, adaptive, stage, stage_doubles);
 }

@@ -2,7 +2,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ek_lane.h"
-#include "filter_team.h"
 #include "team.h"
 #include "dense_lane.h"
 #include "sample_lane.h"
@@ -45,7 +44,6 @@ const TeamLaunch* team_pleiades();  // d = 28 (BASELINE config 4)
 const TeamLaunch* team_lorenz96();  // d = 16: the same kernels on a second shape
 const TeamLaunch* team_launch(int rhs_id);  // nullptr: the field runs on the lane / row-team kernels
 // ... and Pleiades' own entry points (d = 28)
-int launch_filter_pleiades(int q, int ek1, const TeamFilterParams& TP, hipStream_t s);        // global-workspace team kernel
 int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive = 0, double* stage = nullptr,
                                  size_t stage_doubles = 0);  // register-tiled kernel (default)
 int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s);
@@ -53,5 +51,4 @@ int launch_smooth_d28_staged(int q, const SmoothParams& P, long n_rec, double* w
 int launch_dense_d28(int q, const DenseParams& P, double* ws, hipStream_t s);  // ws: dense_d28_grid(N n_q) x team_smooth_ws_doubles
 long dense_d28_grid(long items);
 int launch_sample_d28(int q, const SampleParams& P, double* ws, hipStream_t s);  // ws: dense_d28_grid(N n_samples) x team_smooth_ws_doubles
-size_t team_filter_ws_doubles(int d, int q);
 }  // namespace odef

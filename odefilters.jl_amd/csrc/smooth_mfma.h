@@ -11,8 +11,8 @@
 //   m^s = m + G (m^s_{i+1} - A m)
 //   Sigma^s = X + G M G'                two products Z = M Gt, R = Z' Gt (M symmetric)               [4 D^3]
 //
-// The first version of this smoother (csrc/smooth_team.h, kept as ODEF_PLEIADES_SMOOTH=team for A/B and as what the
-// host emulation runs) does the same algebra with 7 x 7 register tiles of vector FMAs and per-row substitutions out of
+// The first version of this smoother (csrc/smooth_team.h, out of the library; what the host
+// emulation, tests/emul, runs) does the same algebra with 7 x 7 register tiles of vector FMAs and per-row substitutions out of
 // a global workspace: 1.57e5 steps/s.  The textbook form X + G (S^s_+ - S^-) G' is the identity the reference's own test
 // asserts for its stacked-QR Joseph form (test/filtering.jl:113).
 //

@@ -1,6 +1,6 @@
 // Host-side launch paths of the workgroup-per-trajectory kernels (matrix-core filter / smoother / dense output / sampler,
 // record stage), written once for any vector field with an even d <= 32 and instantiated per field (inst_pleiades.hip: d = 28,
-// with the VALU kernels of round 1 as alternates; inst_lorenz96.hip: d = 16, matrix cores only).
+// with the register-tiled VALU filter of round 1 as an alternate; inst_lorenz96.hip: d = 16, matrix cores only).
 #pragma once
 #include "ek_kernels.h"
 
@@ -42,13 +42,13 @@ int team_filter_staged(int q, int ek1, const FilterParams& P, hipStream_t s, int
 // -> [records out].  `n_rec`: number of save slots in use (fixed grids: n_save; adaptive: the largest nsaved of the
 // ensemble -- every trajectory joins in at the block that holds its own last record).  stage_doubles must hold at
 // least two records.
-template <int d, bool VALU_ALTERNATES>
+template <int d>
 int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s) {
   const long n = n_rec, N = P0.N;
   const long D = (long)d * (q + 1), TRI = D * (D + 1) / 2, ld = stage_record_ld(TRI);
   const size_t per_rec = (size_t)N * (size_t)ld;
   const long cap = (long)(stage_doubles / per_rec);
-  if (n < 2 || n > P0.n_save || cap < 2 || (VALU_ALTERNATES && pleiades_smooth_team())) return -4;  // the caller runs the pass on the records in place
+  if (n < 2 || n > P0.n_save || cap < 2) return -4;  // the caller runs the pass on the records in place
   // record 0 is never smoothed (src/smoothing.jl:11) and never staged: copied here (a trajectory that has no other record
   // is not visited by any launch)
   if (hipMemcpyAsync(P0.scov, P0.cov, (size_t)TRI * (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return -5;
@@ -63,7 +63,7 @@ int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, do
     P.stage_ld = ld;
     launch_stage_copy(true, P0.cov + (size_t)lo * TRI * N, stage, N, TRI, ld, hi - lo + 1, s);
     if (!pleiades_smooth_split()) {
-      LaunchTeamSmoothT<VALU_ALTERNATES> f{P, ws, s};
+      LaunchTeamSmooth f{P, ws, s};
       const int rc = dispatch_smooth_order<d>(q, f);
       if (rc) return rc;
     } else {
@@ -73,7 +73,7 @@ int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, do
       P.split_mode = 1;
       P.split_sc = P.split_sa = -1;
       {
-        LaunchTeamSmoothT<VALU_ALTERNATES> f{P, ws, s};
+        LaunchTeamSmooth f{P, ws, s};
         const int rc = dispatch_smooth_order<d>(q, f);
         if (rc) return rc;
       }
@@ -83,7 +83,7 @@ int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, do
         P.split_sc = r + 1 <= r_hi ? r + 1 : -1;
         P.split_sa = r >= r_lo ? r : -1;
         {
-          LaunchTeamSmoothT<VALU_ALTERNATES> f{P, ws, s};
+          LaunchTeamSmooth f{P, ws, s};
           const int rc = dispatch_smooth_order<d>(q, f);
           if (rc) return rc;
         }
@@ -100,9 +100,9 @@ int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, do
   return 0;
 }
 
-template <int d, bool VALU_ALTERNATES>
+template <int d>
 int team_smooth_inplace(int q, const SmoothParams& P, double* ws, hipStream_t s) {
-  LaunchTeamSmoothT<VALU_ALTERNATES> f{P, ws, s};
+  LaunchTeamSmooth f{P, ws, s};
   return dispatch_smooth_order<d>(q, f);
 }
 template <int d>
@@ -115,23 +115,14 @@ int team_sample(int q, const SampleParams& P, double* ws, hipStream_t s) {
   LaunchTeamSample f{P, ws, s};
   return dispatch_smooth_order<d>(q, f);
 }
-template <int d, bool VALU_ALTERNATES>
+template <int d>
 size_t team_smooth_ws(int q) {
-  auto one = [](auto nbc) -> size_t {
-    constexpr int NB = decltype(nbc)::value;
-    size_t a = MfmaSmoothWs<d, NB>::size;
-    if constexpr (VALU_ALTERNATES) {  // the larger of the two smoothers' workspaces (smooth_team.h: 3 D x D matrices; smooth_mfma.h: 7 padded ones)
-      const size_t b = (size_t)SmoothWs<d, NB>::size;
-      a = a > b ? a : b;
-    }
-    return a;
-  };
   switch (q) {
-    case 1: return one(std::integral_constant<int, 2>{});
-    case 2: return one(std::integral_constant<int, 3>{});
-    case 3: return one(std::integral_constant<int, 4>{});
-    case 4: return one(std::integral_constant<int, 5>{});
-    case 5: return one(std::integral_constant<int, 6>{});
+    case 1: return MfmaSmoothWs<d, 2>::size;
+    case 2: return MfmaSmoothWs<d, 3>::size;
+    case 3: return MfmaSmoothWs<d, 4>::size;
+    case 4: return MfmaSmoothWs<d, 5>::size;
+    case 5: return MfmaSmoothWs<d, 6>::size;
     default: return 0;
   }
 }

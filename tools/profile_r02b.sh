@@ -11,7 +11,7 @@ python3 tools/configs_r02.py --only 2,3x8,5,5x8,3s,4 > $OUT/configs.jsonl 2>$OUT
 ODEF_PLEIADES_FILTER=tiles python3 tools/configs_r02.py --only 4 > $OUT/config4_tiles.jsonl 2>>$OUT/configs.err
 for k in 1 2 3; do python3 bench.py > $OUT/bench_$k.json 2>$OUT/bench_$k.err; cut -c1-400 $OUT/bench_$k.json; done
 python3 tools/bench_modes.py --traj 2048 --nsteps 64 --modes pleiades_smooth > $OUT/pleiades_smooth.json 2>>$OUT/configs.err
-ODEF_PLEIADES_SMOOTH=team python3 tools/bench_modes.py --traj 2048 --nsteps 64 --modes pleiades_smooth >> $OUT/pleiades_smooth.json 2>>$OUT/configs.err
+# (round 2 only: the switch left the library in round 3) ODEF_PLEIADES_SMOOTH=team python3 tools/bench_modes.py --traj 2048 --nsteps 64 --modes pleiades_smooth >> $OUT/pleiades_smooth.json 2>>$OUT/configs.err
 cat $OUT/pleiades_smooth.json | cut -c1-300
 timeout -k 5 100 tools/mfma_filter_stamps > $OUT/mfma_filter_stamps.txt 2>&1
 timeout -k 5 60 tools/mfma_dense_test > $OUT/mfma_dense_test.txt 2>&1; timeout -k 5 60 tools/mfma_layout_test > $OUT/mfma_layout_test.txt 2>&1
