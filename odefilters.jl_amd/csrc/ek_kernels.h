@@ -16,6 +16,7 @@
 #include "rows_smooth.h"
 #include "rows_kernels.h"
 #include "smooth_mfma.h"
+#include "smooth_onchip.h"
 #include "dense_rows.h"
 #include "sample_rows.h"
 #ifndef ODEF_HOST_EMUL
@@ -257,9 +258,9 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
   if (i < 0) return;
   double* my = ws + (size_t)i * W::size;
   if ((long)my[W::FLG] != P.split_sa) return;  // (workgroup-uniform) no factor was prepared for this record
-  const int tid = (int)threadIdx.x, wave = tid >> 6, l = tid & 63;
+  const int tid = (int)threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
   const double* BM = my + W::BM;
-  double* YT = my + W::YT;
+  const double* YT = my + W::YT;
   auto tix = [](int j, int jp) { return j * DPB - j * (j - 1) / 2 + (jp - j); };
   // all threads load: element e of tile t = (j, jp >= j) in row order; block row j from t by counting down the row lengths
   for (int e = tid; e < DPB * (DPB + 1) / 2 * 256; e += (int)blockDim.x) {
@@ -359,8 +360,36 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
       asm volatile("" ::: "memory");
     });
   });
+  // What follows the sweeps, still on chip (smooth_onchip.h): G' never leaves the accumulators.
+  //   m^s = P^-1 (P m + G delta)   (src/smoothing.jl:44, :26) -- the carried mean of the pass, read by the workspace kernel
+  //   R = G M G'                   M into the LDS the factor has left, result tiles into BM (full symmetric) for the pack
+  using Pr = oc::Products<DPB>;
+  constexpr int D = W::D;
+  __syncthreads();  // every wavefront is done with the factor
+  double* dl = lds + Pr::size;
+  for (int k = tid; k < DP; k += (int)blockDim.x) dl[k] = k < D ? my[W::DLV + k] : 0.0;  // (nothing defined behind the state dimension)
+  oc::load_m<DPB>(my + W::MM, DP, lds);
+  __syncthreads();
+  {
+    const double t = oc::gt_times<DPB>(acc, dl);
+    const int k = c0 + (l & 15);
+    if (l < 16 && k < D) {
+      const double v = (my[W::MFV + k] + t) * my[W::PIJV + k];
+      my[W::MSV + k] = v;
+      if (!(v == v)) P.retcode[i] = 3;  // "NaNs after smoothing" (src/smoothing.jl:25)
+    }
+  }
+  mf::d4 r[Pr::WMAX];
+  oc::gmgt<DPB>(acc, lds, r);
+  double* BMw = my + W::BM;
 #pragma unroll
-  for (int j = 0; j < DPB; ++j) mf::store_tile(YT, DP, j * mf::kB, c0, acc[j]);
+  for (int w = 0; w < Pr::WMAX; ++w) {
+    if (w < Pr::owned(wave)) {
+      const int cw = wave + w < DPB ? wave + w : wave + w - DPB;
+      mf::store_tile(BMw, DP, cw * mf::kB, c0, r[w]);
+      if (cw != wave) mf::store_tile_t(BMw, DP, c0, cw * mf::kB, r[w]);
+    }
+  }
 }
 inline bool pleiades_smooth_split() {  // the staged pass as a sequence of kernels per record (default); ODEF_SMOOTH_SPLIT=0: one persistent launch per block
   const char* e = getenv("ODEF_SMOOTH_SPLIT");
@@ -429,7 +458,10 @@ struct LaunchTeamSmoothSweeps {
   template <int d, int q>
   void operator()() {
     using W = MfmaSmoothWs<d, q + 1>;
-    constexpr size_t lds_bytes = ((size_t)(W::DPB * (W::DPB + 1) / 2) * mf::kB * 17 + 272) * sizeof(double);
+    // the factor (tile rows padded to 17 doubles) and its scratch; then M, the row buffer(s) of Z and delta (smooth_onchip.h)
+    constexpr size_t lds_factor = (size_t)(W::DPB * (W::DPB + 1) / 2) * mf::kB * 17 + 272, lds_products = (size_t)oc::Products<W::DPB>::size + W::DP;
+    constexpr size_t lds_bytes = (lds_factor > lds_products ? lds_factor : lds_products) * sizeof(double);
+    static_assert(lds_bytes <= 160 * 1024, "the on-chip record step does not fit the LDS");
     // (set at every launch: the attribute belongs to the current device, and a group of contexts spans several)
     if (hipFuncSetAttribute((const void*)rts_smooth_sweeps_kernel<d, q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
       rc = -6;

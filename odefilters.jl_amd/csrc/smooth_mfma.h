@@ -203,11 +203,18 @@ __device__ __attribute__((always_inline)) inline bool mfma_gain_phase(double* __
   ODEF_STAMP(4);  // sweeps
   }
   // m^s = m + G delta (src/smoothing.jl:44), un-preconditioned (:26)
+  // (four running sums over the rows r = 0, 1, 2, 3 mod 4, combined as (s0 + s1) + (s2 + s3): the order in which the on-chip
+  // kernel of the split pass, oc::gt_times, sums the same terms from its accumulator tiles -- un-preconditioning amplifies
+  // rounding differences by h^-j in derivative block j, and the two passes are compared with each other)
   for (int k = tid; k < D; k += nth) {
-    double t = mf_[k];
-#pragma unroll 8
-    for (int r = 0; r < D; ++r) t += YT[r * DP + k] * dl_[r];
-    const double v = t * pij_[k];
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+    for (int r = 0; r < D; r += 4) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (D % 4 == 0 || r + g < D) s4[g] = fma(YT[(r + g) * DP + k], dl_[r + g], s4[g]);
+    }
+    const double v = (mf_[k] + ((s4[0] + s4[1]) + (s4[2] + s4[3]))) * pij_[k];
     nan_seen = nan_seen || !(v == v);
     ms_[k] = v;
   }
@@ -397,13 +404,10 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
   auto part_c = [&](long s, auto split) {
     constexpr bool SPLIT = decltype(split)::value;
     if constexpr (SPLIT) {
-      for (int k = tid; k < DP; k += nth) {
-        mf_[k] = ws[W::MFV + k];
-        dl_[k] = ws[W::DLV + k];
-        pij_[k] = ws[W::PIJV + k];
-      }
+      // the smoothed mean (in ms_ since the start of this launch, from W::MSV) and R = G M G' (in BM) were left by
+      // rts_smooth_sweeps_kernel, which also raises the NaN return code
+      for (int k = tid; k < DP; k += nth) pij_[k] = ws[W::PIJV + k];
       __syncthreads();
-      nan_seen = mfma_gain_phase<d, q, 4>(ws, lds) || nan_seen;
     }
     for (int k = tid; k < D; k += nth) P.smean[((size_t)s * D + k) * N + i] = ms_[k];
     // Sigma^s = P^-1 (X + G M G') P^-1: the record (packed lower triangle) and the carried full matrix
