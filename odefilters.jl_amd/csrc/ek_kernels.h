@@ -361,33 +361,63 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
     });
   });
   // What follows the sweeps, still on chip (smooth_onchip.h): G' never leaves the accumulators.
-  //   m^s = P^-1 (P m + G delta)   (src/smoothing.jl:44, :26) -- the carried mean of the pass, read by the workspace kernel
-  //   R = G M G'                   M into the LDS the factor has left, result tiles into BM (full symmetric) for the pack
+  //   m^s = P^-1 (P m + G delta)          (src/smoothing.jl:44, :26) -- the record and the carried mean of the pass
+  //   Sigma^s = P^-1 (X + G M G') P^-1    M into the LDS the factor has left; the result tiles go straight to the record in
+  //                                       the stage (packed lower triangle) and to the carried full matrix SG
   using Pr = oc::Products<DPB>;
   constexpr int D = W::D;
+  const size_t N = (size_t)P.N;
+  const long s = P.split_sa;
   __syncthreads();  // every wavefront is done with the factor
   double* dl = lds + Pr::size;
-  for (int k = tid; k < DP; k += (int)blockDim.x) dl[k] = k < D ? my[W::DLV + k] : 0.0;  // (nothing defined behind the state dimension)
+  double* pij = dl + DP;
+  for (int k = tid; k < DP; k += (int)blockDim.x) {  // (nothing is defined behind the state dimension)
+    dl[k] = k < D ? my[W::DLV + k] : 0.0;
+    pij[k] = k < D ? my[W::PIJV + k] : 0.0;
+  }
   oc::load_m<DPB>(my + W::MM, DP, lds);
   __syncthreads();
   {
     const double t = oc::gt_times<DPB>(acc, dl);
     const int k = c0 + (l & 15);
     if (l < 16 && k < D) {
-      const double v = (my[W::MFV + k] + t) * my[W::PIJV + k];
+      const double v = (my[W::MFV + k] + t) * pij[k];
       my[W::MSV + k] = v;
+      P.smean[((size_t)s * D + k) * N + (size_t)i] = v;
       if (!(v == v)) P.retcode[i] = 3;  // "NaNs after smoothing" (src/smoothing.jl:25)
     }
   }
   mf::d4 r[Pr::WMAX];
   oc::gmgt<DPB>(acc, lds, r);
-  double* BMw = my + W::BM;
+  const double* X = my + W::X;
+  double* SG = my + W::SG;
+  double* dst = P.stage + ((size_t)(s - P.stage_s0) * N + (size_t)i) * (size_t)P.stage_ld;
 #pragma unroll
   for (int w = 0; w < Pr::WMAX; ++w) {
     if (w < Pr::owned(wave)) {
-      const int cw = wave + w < DPB ? wave + w : wave + w - DPB;
-      mf::store_tile(BMw, DP, cw * mf::kB, c0, r[w]);
-      if (cw != wave) mf::store_tile_t(BMw, DP, c0, cw * mf::kB, r[w]);
+      const int cw = wave + w < DPB ? wave + w : wave + w - DPB;  // tile (cw, wave) of the sum: below the diagonal unless the window wrapped
+      const mf::d4 x = mf::load_tile(X, DP, cw * mf::kB, c0);
+      mf::d4 o;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int a = cw * mf::kB + 4 * v + (l >> 4), b = c0 + (l & 15);
+        o[v] = (x[v] + r[w][v]) * (pij[a] * pij[b]);
+        const int hi = a > b ? a : b, lo = a > b ? b : a;
+        if (hi < D && (cw != wave || b <= a)) dst[hi * (hi + 1) / 2 + lo] = o[v];
+      }
+      if (cw != wave) {
+        mf::store_tile(SG, DP, cw * mf::kB, c0, o);
+        mf::store_tile_t(SG, DP, c0, cw * mf::kB, o);
+      } else {  // a diagonal tile: its lower triangle is what both halves get (the record holds nothing else)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int a = c0 + 4 * v + (l >> 4), b = c0 + (l & 15);
+          if (b <= a) {
+            SG[a * DP + b] = o[v];
+            SG[b * DP + a] = o[v];
+          }
+        }
+      }
     }
   }
 }
@@ -459,7 +489,7 @@ struct LaunchTeamSmoothSweeps {
   void operator()() {
     using W = MfmaSmoothWs<d, q + 1>;
     // the factor (tile rows padded to 17 doubles) and its scratch; then M, the row buffer(s) of Z and delta (smooth_onchip.h)
-    constexpr size_t lds_factor = (size_t)(W::DPB * (W::DPB + 1) / 2) * mf::kB * 17 + 272, lds_products = (size_t)oc::Products<W::DPB>::size + W::DP;
+    constexpr size_t lds_factor = (size_t)(W::DPB * (W::DPB + 1) / 2) * mf::kB * 17 + 272, lds_products = (size_t)oc::Products<W::DPB>::size + 2 * W::DP;
     constexpr size_t lds_bytes = (lds_factor > lds_products ? lds_factor : lds_products) * sizeof(double);
     static_assert(lds_bytes <= 160 * 1024, "the on-chip record step does not fit the LDS");
     // (set at every launch: the attribute belongs to the current device, and a group of contexts spans several)

@@ -450,10 +450,10 @@ struct SmoothParams {
                    // has (of its 1 .. n - 2); a trajectory whose last record n - 1 lies in the stage starts its carried state
                    // from it, one whose last record lies above continues from the workspace, one below has nothing to do yet
   // the same pass as a sequence of kernels per record (the default; ODEF_SMOOTH_SPLIT=0 turns it off; smooth_mfma.h): 0 = one persistent launch per block;
-  // 1 = set up / carry over the block's state only; 2 = finish record split_sc (mean, products, pack), then begin record
-  // split_sa (unpack, predict, Cholesky) -- the sweeps between the two run in a kernel of their own with the factor in LDS
+  // 1 = set up / carry over the block's state only; 2 = begin record split_sa (unpack, predict) -- everything that follows
+  // (factorisation, sweeps, mean, G M G', the smoothed record) runs on chip in rts_smooth_sweeps_kernel, launched behind it
   int split_mode;
-  long split_sc, split_sa;  // -1: none
+  long split_sc, split_sa;  // split_sa: the record of this pair of launches; split_sc: unused since round 3 (-1)
 };
 
 }  // namespace odef

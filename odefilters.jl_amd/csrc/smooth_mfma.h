@@ -403,12 +403,7 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
   // part C: smoothed mean, the two products, pack and store
   auto part_c = [&](long s, auto split) {
     constexpr bool SPLIT = decltype(split)::value;
-    if constexpr (SPLIT) {
-      // the smoothed mean (in ms_ since the start of this launch, from W::MSV) and R = G M G' (in BM) were left by
-      // rts_smooth_sweeps_kernel, which also raises the NaN return code
-      for (int k = tid; k < DP; k += nth) pij_[k] = ws[W::PIJV + k];
-      __syncthreads();
-    }
+    static_assert(!SPLIT, "the split pass finishes its records in rts_smooth_sweeps_kernel");
     for (int k = tid; k < D; k += nth) P.smean[((size_t)s * D + k) * N + i] = ms_[k];
     // Sigma^s = P^-1 (X + G M G') P^-1: the record (packed lower triangle) and the carried full matrix
     if (staged) {  // by tiles, as the unpacking above; the lower triangle of the sum is what both halves of SG get
@@ -459,7 +454,9 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
     // the hand-over flag: the record index part A prepared (-1: none, or a repeated save time)
     const long prepared = (long)ws[W::FLG];
     __syncthreads();
-    if (P.split_sc >= s_lo && P.split_sc <= s_hi && prepared == P.split_sc) part_c(P.split_sc, std::true_type{});
+    // (part C of the record the sweeps kernel has just been through -- smoothed mean, Sigma^s = X + G M G', the record in
+    // the stage and the carried SG -- was finished there, on chip)
+    (void)prepared;
     bool active = false;
     if (P.split_sa >= s_lo && P.split_sa <= s_hi) active = part_a(P.split_sa, std::true_type{});
     __syncthreads();

@@ -68,8 +68,8 @@ int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, do
       if (rc) return rc;
     } else {
       // one kernel per phase and record: [set up the block] then, record by record from the top,
-      // [finish record r + 1 | begin record r] -> [sweeps of record r with the factor in LDS]; trajectories that do not have
-      // the record (adaptive solves) or repeat a save time skip their part inside the kernels
+      // [begin record r: unpack, predict] -> [the rest of record r on chip: factor, sweeps, mean, G M G', the record];
+      // trajectories that do not have the record (adaptive solves) or repeat a save time skip their part inside the kernels
       P.split_mode = 1;
       P.split_sc = P.split_sa = -1;
       {
@@ -79,19 +79,17 @@ int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, do
       }
       const long r_hi = hi < n - 2 ? hi : n - 2, r_lo = lo;
       P.split_mode = 2;
-      for (long r = r_hi; r >= r_lo - 1; --r) {
-        P.split_sc = r + 1 <= r_hi ? r + 1 : -1;
-        P.split_sa = r >= r_lo ? r : -1;
+      for (long r = r_hi; r >= r_lo; --r) {
+        P.split_sc = -1;
+        P.split_sa = r;
         {
           LaunchTeamSmooth f{P, ws, s};
           const int rc = dispatch_smooth_order<d>(q, f);
           if (rc) return rc;
         }
-        if (P.split_sa >= 0) {
-          LaunchTeamSmoothSweeps g{P, ws, s};
-          const int rc = dispatch_smooth_order<d>(q, g);
-          if (rc || g.rc) return rc ? rc : g.rc;
-        }
+        LaunchTeamSmoothSweeps g{P, ws, s};
+        const int rc = dispatch_smooth_order<d>(q, g);
+        if (rc || g.rc) return rc ? rc : g.rc;
       }
     }
     launch_stage_copy(false, stage, P0.scov + (size_t)lo * TRI * N, N, TRI, ld, hi - lo + 1, s);
