@@ -244,6 +244,21 @@ __global__ __launch_bounds__(kTeamBig, 4) void rts_smooth_mfma_kernel(const Smoo
   if (i < 0) return;
   smooth_mfma_traj<d, q, SPLITK>(P, i, ws + (size_t)i * W::size, lds);
 }
+#ifdef ODEF_SWEEPS_STAMPS  // diagnostic build (tools/split_smooth_stamps.hip): wall-clock ticks per phase of workgroup 0
+__device__ unsigned long long g_sweeps_stamps[16];
+__device__ unsigned long long g_sweeps_t0;
+#define ODEF_SSTAMP(k)                                                           \
+  do {                                                                           \
+    __syncthreads();                                                             \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                   \
+      const unsigned long long now_ = wall_clock64();                            \
+      if ((k) >= 0) g_sweeps_stamps[(k) < 0 ? 0 : (k)] += now_ - g_sweeps_t0;    \
+      g_sweeps_t0 = now_;                                                        \
+    }                                                                            \
+  } while (0)
+#else
+#define ODEF_SSTAMP(k)
+#endif
 // The Cholesky factorisation and the two block sweeps of ONE record for every trajectory, on chip (split pass, the default of
 // the staged smoother; prototype and measurements of the sweeps: tools/onchip_sweep_proto.hip): one workgroup of DPB
 // wavefronts per trajectory, the upper tiles of B in LDS (rows padded to 17 doubles so that the transposed reads of the
@@ -262,72 +277,107 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
   const double* BM = my + W::BM;
   const double* YT = my + W::YT;
   auto tix = [](int j, int jp) { return j * DPB - j * (j - 1) / 2 + (jp - j); };
-  // all threads load: element e of tile t = (j, jp >= j) in row order; block row j from t by counting down the row lengths
-  for (int e = tid; e < DPB * (DPB + 1) / 2 * 256; e += (int)blockDim.x) {
-    const int t = e >> 8, r = (e >> 4) & 15, c = e & 15;
-    int j = 0, rest = t;
-    while (rest >= DPB - j) {
-      rest -= DPB - j;
-      ++j;
-    }
-    const int jp = j + rest;
-    lds[t * TSZ + r * LDT + c] = BM[(size_t)(j * 16 + r) * DP + jp * 16 + c];
-  }
-  __syncthreads();
-  // B = U'U in LDS, right-looking by block rows: the diagonal tile is factorised by one wavefront and replaced by
-  // W_j = L_jj^-1 (what the sweeps multiply with), the tiles of block row j become U[j, .] = W_j (.), the tiles below take
-  // their rank-16 update.  1 100 MFMAs in all; what it costs is the 11 diagonal factorisations in sequence.
-  {
-    double* scratch = lds + DPB * (DPB + 1) / 2 * TSZ;  // 16 x 16 block + 16 reciprocals for diag_block_factor
-    const int nw = (int)blockDim.x >> 6;
-    for (int j = 0; j < DPB; ++j) {
-      double* tjj = lds + tix(j, j) * TSZ;
-      if (wave == 0) {
-        for (int e = l; e < 256; e += 64) scratch[e] = tjj[(e >> 4) * LDT + (e & 15)];
-        tv::lds_sync();
-        mf::diag_block_factor(scratch, nullptr, tjj, LDT);
-      }
-      __syncthreads();
-      for (int jp = j + 1 + wave; jp < DPB; jp += nw) {
-        double* t = lds + tix(j, jp) * TSZ;
-        mf::d4 r, u = mf::zero4();
-#pragma unroll
-        for (int v = 0; v < 4; ++v) r[v] = t[(4 * v + (l >> 4)) * LDT + (l & 15)];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) u = mf::mfma(tjj[(l & 15) * LDT + 4 * kk + (l >> 4)], r[kk], u);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) t[(4 * v + (l >> 4)) * LDT + (l & 15)] = u[v];
-      }
-      __syncthreads();
-      const int m = DPB - 1 - j;
-      for (int t = wave; t < m * (m + 1) / 2; t += nw) {
-        int a = j + 1, rest = t;
-        while (rest >= DPB - a) {
-          rest -= DPB - a;
-          ++a;
-        }
-        const int b = a + rest;
-        const double* ua = lds + tix(j, a) * TSZ;
-        const double* ub = lds + tix(j, b) * TSZ;
-        double* tab = lds + tix(a, b) * TSZ;
-        mf::d4 acc;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] = tab[(4 * v + (l >> 4)) * LDT + (l & 15)];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int o = (4 * ks + (l >> 4)) * LDT + (l & 15);
-          acc = mf::mfma(-ua[o], ub[o], acc);
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) tab[(4 * v + (l >> 4)) * LDT + (l & 15)] = acc[v];
-      }
-      __syncthreads();
-    }
-  }
+  ODEF_SSTAMP(-1);
+  // B -> LDS, upper tiles in row order, wavefront w takes the tiles w, w + DPB, ...: all its loads in flight, then the stores.
+  // Behind them (loads return in order) the right-hand sides: tile column `wave` of Y' = A X goes to the accumulators, where
+  // it stays until the record is done; those loads complete beside the factorisation.
   const int c0 = wave * mf::kB;
   mf::d4 acc[DPB];
+  {
+    constexpr int NTU = DPB * (DPB + 1) / 2, PER = (NTU + DPB - 1) / DPB;
+    mf::d4 x[PER];
 #pragma unroll
-  for (int j = 0; j < DPB; ++j) acc[j] = mf::load_tile(YT, DP, j * mf::kB, c0);
+    for (int u = 0; u < PER; ++u) {
+      const int t = wave + u * DPB;
+      int j = 0, rest = t;
+      while (rest >= DPB - j) {  // block row j from t by counting down the row lengths (wavefront-uniform)
+        rest -= DPB - j;
+        ++j;
+      }
+      if (t < NTU) x[u] = mf::load_tile(BM, DP, j * mf::kB, (j + rest) * mf::kB);
+    }
+#pragma unroll
+    for (int j = 0; j < DPB; ++j) acc[j] = mf::load_tile(YT, DP, j * mf::kB, c0);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int t = wave + u * DPB;
+      if (t < NTU) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) lds[t * TSZ + (4 * v + (l >> 4)) * LDT + (l & 15)] = x[u][v];
+      }
+    }
+  }
+  __syncthreads();
+  ODEF_SSTAMP(0);  // B -> LDS
+  // B = U'U in LDS, right-looking by block rows: the diagonal tile is factorised by wavefront 0 and replaced by
+  // W_j = L_jj^-1 (what the sweeps multiply with), the tiles of block row j become U[j, .] = W_j (.), the tiles below take
+  // their rank-16 update.  1 100 MFMAs in all; what it costs is the 11 diagonal factorisations in sequence -- so wavefront 0
+  // looks ahead: it takes the panel tile (j, j + 1), and while the others update the trailing tiles it updates (j + 1, j + 1)
+  // alone and factorises it.
+  {
+    static_assert(DPB >= 2, "one wavefront factorises, the others update");
+    double* scratch = lds + DPB * (DPB + 1) / 2 * TSZ;  // 16 x 16 block + 16 reciprocals for diag_block_factor
+    const int nw = (int)blockDim.x >> 6;
+    auto diag = [&](int j) {
+      double* tjj = lds + tix(j, j) * TSZ;
+      for (int e = l; e < 256; e += 64) scratch[e] = tjj[(e >> 4) * LDT + (e & 15)];
+      tv::lds_sync();
+      mf::diag_block_factor(scratch, nullptr, tjj, LDT);
+      tv::lds_sync();
+    };
+    auto panel_tile = [&](int j, int jp) {  // U[j, jp] = W_j B[j, jp]
+      const double* tjj = lds + tix(j, j) * TSZ;
+      double* t = lds + tix(j, jp) * TSZ;
+      mf::d4 r, u = mf::zero4();
+#pragma unroll
+      for (int v = 0; v < 4; ++v) r[v] = t[(4 * v + (l >> 4)) * LDT + (l & 15)];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) u = mf::mfma(tjj[(l & 15) * LDT + 4 * kk + (l >> 4)], r[kk], u);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) t[(4 * v + (l >> 4)) * LDT + (l & 15)] = u[v];
+    };
+    auto trail_tile = [&](int j, int a, int b) {  // B[a, b] -= U[j, a]' U[j, b]
+      const double* ua = lds + tix(j, a) * TSZ;
+      const double* ub = lds + tix(j, b) * TSZ;
+      double* tab = lds + tix(a, b) * TSZ;
+      mf::d4 t;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) t[v] = tab[(4 * v + (l >> 4)) * LDT + (l & 15)];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int o = (4 * ks + (l >> 4)) * LDT + (l & 15);
+        t = mf::mfma(-ua[o], ub[o], t);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) tab[(4 * v + (l >> 4)) * LDT + (l & 15)] = t[v];
+    };
+    if (wave == 0) diag(0);
+    __syncthreads();
+    for (int j = 0; j + 1 < DPB; ++j) {
+      if (wave == 0) panel_tile(j, j + 1);
+      else
+        for (int jp = j + 2 + (wave - 1); jp < DPB; jp += nw - 1) panel_tile(j, jp);
+      __syncthreads();
+      if (wave == 0) {
+        trail_tile(j, j + 1, j + 1);
+        tv::lds_sync();
+        diag(j + 1);
+      } else {
+        const int m = DPB - 1 - j;
+        for (int t = wave; t < m * (m + 1) / 2; t += nw - 1) {  // (tile 0 of the trailing block, (j + 1, j + 1), is wavefront 0's)
+          int a = j + 1, rest = t;
+          while (rest >= DPB - a) {
+            rest -= DPB - a;
+            ++a;
+          }
+          trail_tile(j, a, a + rest);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  ODEF_SSTAMP(1);  // factorisation
+  ODEF_SSTAMP(2);  // (the right-hand sides are in the accumulators already)
   static_for<0, DPB>([&](auto jc) {  // forward: Z_j = W_j acc_j, acc_j' -= U[j, j']' Z_j for j' > j
     constexpr int j = decltype(jc)::value;
     const double* w = lds + tix(j, j) * TSZ;
@@ -344,6 +394,7 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
       asm volatile("" ::: "memory");  // keeps the compiler from hoisting (and spilling) the fragment reads of all later tiles
     });
   });
+  ODEF_SSTAMP(3);  // forward sweep
   static_for<0, DPB>([&](auto jc) {  // backward: Gt_j = W_j' acc_j, acc_j' -= U[j', j] Gt_j for j' < j
     constexpr int j = DPB - 1 - decltype(jc)::value;
     const double* w = lds + tix(j, j) * TSZ;
@@ -360,6 +411,7 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
       asm volatile("" ::: "memory");
     });
   });
+  ODEF_SSTAMP(4);  // backward sweep
   // What follows the sweeps, still on chip (smooth_onchip.h): G' never leaves the accumulators.
   //   m^s = P^-1 (P m + G delta)          (src/smoothing.jl:44, :26) -- the record and the carried mean of the pass
   //   Sigma^s = P^-1 (X + G M G') P^-1    M into the LDS the factor has left; the result tiles go straight to the record in
@@ -377,6 +429,7 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
   }
   oc::load_m<DPB>(my + W::MM, DP, lds);
   __syncthreads();
+  ODEF_SSTAMP(5);  // M, vectors -> LDS
   {
     const double t = oc::gt_times<DPB>(acc, dl);
     const int k = c0 + (l & 15);
@@ -387,39 +440,59 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
       if (!(v == v)) P.retcode[i] = 3;  // "NaNs after smoothing" (src/smoothing.jl:25)
     }
   }
+  ODEF_SSTAMP(6);  // mean
   mf::d4 r[Pr::WMAX];
   oc::gmgt<DPB>(acc, lds, r);
+  ODEF_SSTAMP(7);  // G M G'
   const double* X = my + W::X;
   double* SG = my + W::SG;
   double* dst = P.stage + ((size_t)(s - P.stage_s0) * N + (size_t)i) * (size_t)P.stage_ld;
+  mf::d4 x[Pr::WMAX];
+#pragma unroll
+  for (int w = 0; w < Pr::WMAX; ++w) {
+    const int cw = wave + w < DPB ? wave + w : wave + w - DPB;
+    if (w < Pr::owned(wave)) x[w] = mf::load_tile(X, DP, cw * mf::kB, c0);
+  }
+  __syncthreads();  // every wavefront is done with M and the row buffer: each takes 16 x 17 doubles of LDS to transpose its tiles in
+  double* tr = lds + wave * TSZ;
 #pragma unroll
   for (int w = 0; w < Pr::WMAX; ++w) {
     if (w < Pr::owned(wave)) {
-      const int cw = wave + w < DPB ? wave + w : wave + w - DPB;  // tile (cw, wave) of the sum: below the diagonal unless the window wrapped
-      const mf::d4 x = mf::load_tile(X, DP, cw * mf::kB, c0);
-      mf::d4 o;
+      // tile (cw, wave) of the sum and, through LDS, its transpose (wave, cw): both leave as whole 128-byte rows.  The record
+      // (packed lower triangle) takes whichever of the two lies below the diagonal -- the transpose if the window wrapped.
+      const int cw = wave + w < DPB ? wave + w : wave + w - DPB;
+      mf::d4 o, ot;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int a = cw * mf::kB + 4 * v + (l >> 4), b = c0 + (l & 15);
-        o[v] = (x[v] + r[w][v]) * (pij[a] * pij[b]);
-        const int hi = a > b ? a : b, lo = a > b ? b : a;
-        if (hi < D && (cw != wave || b <= a)) dst[hi * (hi + 1) / 2 + lo] = o[v];
+        o[v] = (x[w][v] + r[w][v]) * (pij[a] * pij[b]);
+        tr[(4 * v + (l >> 4)) * LDT + (l & 15)] = o[v];
       }
-      if (cw != wave) {
-        mf::store_tile(SG, DP, cw * mf::kB, c0, o);
-        mf::store_tile_t(SG, DP, c0, cw * mf::kB, o);
-      } else {  // a diagonal tile: its lower triangle is what both halves get (the record holds nothing else)
+      tv::lds_sync();
+#pragma unroll
+      for (int v = 0; v < 4; ++v) ot[v] = tr[(l & 15) * LDT + 4 * v + (l >> 4)];
+      tv::lds_sync();
+      if (cw == wave) {  // a diagonal tile: its lower triangle is what both halves get (the record holds nothing else)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           const int a = c0 + 4 * v + (l >> 4), b = c0 + (l & 15);
-          if (b <= a) {
-            SG[a * DP + b] = o[v];
-            SG[b * DP + a] = o[v];
-          }
+          if (b > a) o[v] = ot[v];
+          if (b <= a && a < D) dst[a * (a + 1) / 2 + b] = o[v];
         }
+        mf::store_tile(SG, DP, c0, c0, o);
+      } else {
+        const bool lower = cw > wave;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int a = (lower ? cw * mf::kB : c0) + 4 * v + (l >> 4), b = (lower ? c0 : cw * mf::kB) + (l & 15);
+          if (a < D) dst[a * (a + 1) / 2 + b] = lower ? o[v] : ot[v];
+        }
+        mf::store_tile(SG, DP, cw * mf::kB, c0, o);
+        mf::store_tile(SG, DP, c0, cw * mf::kB, ot);
       }
     }
   }
+  ODEF_SSTAMP(8);  // X + R, record, carried matrix
 }
 inline bool pleiades_smooth_split() {  // the staged pass as a sequence of kernels per record (default); ODEF_SMOOTH_SPLIT=0: one persistent launch per block
   const char* e = getenv("ODEF_SMOOTH_SPLIT");

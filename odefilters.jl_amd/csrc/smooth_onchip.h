@@ -38,25 +38,32 @@ struct Products {
   __host__ __device__ static constexpr int sw(int r, int c) { return r * 16 + (c ^ ((r >> 1) << 1)); }
 };
 
-// M (full symmetric DP x DP, row-major, leading dimension ld) -> LDS, upper tiles; all wavefronts of the workgroup
+// M (full symmetric DP x DP, row-major, leading dimension ld) -> LDS, upper tiles in row order; the workgroup has DPB
+// wavefronts, wavefront w takes the tiles w, w + DPB, ...: all its loads in flight, then the stores
 template <int DPB>
 __device__ __attribute__((always_inline)) inline void load_m(const double* __restrict__ MM, int ld, double* __restrict__ lds) {
   using Pr = Products<DPB>;
-  const int tid = (int)threadIdx.x, wave = tid >> 6, nw = (int)blockDim.x >> 6, l = tid & 63;
-  int j = 0, jp = 0;
-  auto next = [&]() {
-    if (++jp >= DPB) {
-      ++j;
-      jp = j;
-    }
-  };
-  for (int t = 0; t < wave; ++t) next();
-  for (int t = wave; t < Pr::NTU; t += nw) {
-    const d4 x = mf::load_tile(MM, ld, j * 16, jp * 16);
-    double* dst = lds + Pr::kM + t * 256;
+  constexpr int PER = (Pr::NTU + DPB - 1) / DPB;
+  const int tid = (int)threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+  d4 x[PER];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) dst[Pr::sw(4 * v + (l >> 4), l & 15)] = x[v];
-    for (int k = 0; k < nw; ++k) next();
+  for (int u = 0; u < PER; ++u) {
+    const int t = wave + u * DPB;
+    int j = 0, rest = t;
+    while (rest >= DPB - j) {  // block row j from t by counting down the row lengths (wavefront-uniform)
+      rest -= DPB - j;
+      ++j;
+    }
+    if (t < Pr::NTU) x[u] = mf::load_tile(MM, ld, j * 16, (j + rest) * 16);
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int t = wave + u * DPB;
+    if (t < Pr::NTU) {
+      double* dst = lds + Pr::kM + t * 256;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) dst[Pr::sw(4 * v + (l >> 4), l & 15)] = x[u][v];
+    }
   }
 }
 
