@@ -69,6 +69,7 @@ struct odef_ctx {
   JitModule* jit = nullptr; // run-time compiled vector field (rhs_id >= 100); owned by the registry in jit.hip
   double* d_ws = nullptr;   // per-trajectory workspace of the team kernels
   double* d_stage = nullptr;  // trajectory-major stage of the covariance records (D = 168 smoother, record_stage.h)
+  long stage_filter_recs = 0; // > 0: the last solve left this many filter records in the stage (record r at r N ld)
   size_t stage_cap = 0;     // doubles
   size_t ws_cap = 0;
   Buf f[ODEF_F_COUNT_];
@@ -511,6 +512,7 @@ static int finish_filter(odef_ctx* c, int nlaunch) {
                        (double*)c->f[ODEF_F_LOGLIK].ptr, c->adaptive ? (const int*)c->f[ODEF_F_NSAVED].ptr : (const int*)nullptr,
                        N, c->n_save, c->TRI);
     ++nlaunch;
+    c->stage_filter_recs = 0;  // (records the filter may have left in the stage are the unscaled ones)
   }
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   HIPCHK(c, hipGetLastError());
@@ -600,7 +602,7 @@ int odef_solve_fixed(odef_ctx* c, const double* tgrid, int64_t n_t) {
       if (have < (size_t)(nsteps + 1) * per_rec) have = 0;
     }
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    rc = c->team->filter(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 0, have ? c->d_stage : nullptr, have);
+    rc = c->team->filter(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 0, have ? c->d_stage : nullptr, have, &c->stage_filter_recs);
   } else {
     // one lane per trajectory: the per-field buffer descriptors carry 32-bit sizes
     if ((size_t)c->TRI * (size_t)c->cfg.n_traj * sizeof(double) >= (1ull << 31))
@@ -658,7 +660,7 @@ int odef_solve_adaptive(odef_ctx* c, double t1, double abstol, double reltol, do
     note_kernel("odef_jit_adaptive");
     rc = jit_launch(c->jit->adaptive, (unsigned)((P.N + 63) / 64), 1, &P, c->stream);
   } else {
-    rc = c->team_path ? c->team->filter(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 1, nullptr, 0)
+    rc = c->team_path ? c->team->filter(c->q, c->cfg.alg == ODEF_EK1, P, c->stream, 1, nullptr, 0, &c->stage_filter_recs)
                       : launch_filter(c->cfg.rhs_id, c->q, c->cfg.alg == ODEF_EK1, 1, P, c->stream);
   }
   if (rc) return fail(c, "odef_solve_adaptive: no kernel for rhs %d order %d", c->cfg.rhs_id, c->q);
@@ -723,8 +725,12 @@ int odef_smooth(odef_ctx* c) {
         if (n_rec > S.n_save) n_rec = S.n_save;
       }
       const size_t tri = (size_t)c->D * (c->D + 1) / 2;
-      const size_t have = n_rec < 3 ? 0 : ensure_stage(c, n_rec - 1, (size_t)S.N * ((tri + 15) / 16 * 16));
-      if (have) rc = c->team->smooth_staged(c->q, S, n_rec, c->d_ws, c->d_stage, have, c->stream);
+      const size_t per_rec = (size_t)S.N * ((tri + 15) / 16 * 16);
+      // the filter's records may still be in the stage (fixed grid, every step saved, all of them fit): record r at r * per_rec
+      const bool resident = !S.adaptive && n_rec >= 3 && c->stage_filter_recs == n_rec && c->stage_cap >= (size_t)n_rec * per_rec;
+      const size_t have = n_rec < 3 ? 0 : resident ? (size_t)(n_rec - 1) * per_rec : ensure_stage(c, n_rec - 1, per_rec);
+      if (have) rc = c->team->smooth_staged(c->q, S, n_rec, c->d_ws, c->d_stage, have, c->stream, resident ? n_rec : 0);
+      c->stage_filter_recs = 0;  // (smoothed records now, or another block layout)
     }
     if (rc == -4) rc = c->team->smooth(c->q, S, c->d_ws, c->stream);
   } else

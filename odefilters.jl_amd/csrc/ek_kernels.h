@@ -17,6 +17,7 @@
 #include "rows_kernels.h"
 #include "smooth_mfma.h"
 #include "smooth_onchip.h"
+#include "smooth_predict.h"
 #include "dense_rows.h"
 #include "sample_rows.h"
 #ifndef ODEF_HOST_EMUL
@@ -423,9 +424,11 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
   __syncthreads();  // every wavefront is done with the factor
   double* dl = lds + Pr::size;
   double* pij = dl + DP;
-  for (int k = tid; k < DP; k += (int)blockDim.x) {  // (nothing is defined behind the state dimension)
-    dl[k] = k < D ? my[W::DLV + k] : 0.0;
-    pij[k] = k < D ? my[W::PIJV + k] : 0.0;
+  double* pj = pij + DP;
+  for (int k = tid; k < DP; k += (int)blockDim.x) {  // (zero behind the state dimension, as the predict kernel left them)
+    dl[k] = my[W::DLV + k];
+    pij[k] = my[W::PIJV + k];
+    pj[k] = my[W::PJV + k];
   }
   oc::load_m<DPB>(my + W::MM, DP, lds);
   __syncthreads();
@@ -444,34 +447,50 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
   mf::d4 r[Pr::WMAX];
   oc::gmgt<DPB>(acc, lds, r);
   ODEF_SSTAMP(7);  // G M G'
-  const double* X = my + W::X;
+  // X = P Sigma_s P comes from the record itself (packed lower triangle, still the filter's): the tile below the diagonal of
+  // each pair, whole rows of it contiguous
   double* SG = my + W::SG;
   double* dst = P.stage + ((size_t)(s - P.stage_s0) * N + (size_t)i) * (size_t)P.stage_ld;
   mf::d4 x[Pr::WMAX];
 #pragma unroll
   for (int w = 0; w < Pr::WMAX; ++w) {
     const int cw = wave + w < DPB ? wave + w : wave + w - DPB;
-    if (w < Pr::owned(wave)) x[w] = mf::load_tile(X, DP, cw * mf::kB, c0);
+    if (w < Pr::owned(wave)) {
+      const int tr = cw > wave ? cw : wave, tc = cw > wave ? wave : cw;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int a = tr * mf::kB + 4 * v + (l >> 4), b = tc * mf::kB + (l & 15);
+        x[w][v] = (a < D && b <= a) ? dst[a * (a + 1) / 2 + b] * (pj[a] * pj[b]) : 0.0;
+      }
+    }
   }
   __syncthreads();  // every wavefront is done with M and the row buffer: each takes 16 x 17 doubles of LDS to transpose its tiles in
   double* tr = lds + wave * TSZ;
+  auto transposed = [&](const mf::d4& t) {
+    mf::d4 o;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) tr[(4 * v + (l >> 4)) * LDT + (l & 15)] = t[v];
+    tv::lds_sync();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) o[v] = tr[(l & 15) * LDT + 4 * v + (l >> 4)];
+    tv::lds_sync();
+    return o;
+  };
 #pragma unroll
   for (int w = 0; w < Pr::WMAX; ++w) {
     if (w < Pr::owned(wave)) {
       // tile (cw, wave) of the sum and, through LDS, its transpose (wave, cw): both leave as whole 128-byte rows.  The record
-      // (packed lower triangle) takes whichever of the two lies below the diagonal -- the transpose if the window wrapped.
+      // takes whichever of the two lies below the diagonal -- the transpose if the window wrapped (then X was read as that
+      // transpose too).
       const int cw = wave + w < DPB ? wave + w : wave + w - DPB;
-      mf::d4 o, ot;
+      const mf::d4 xw = cw >= wave ? x[w] : transposed(x[w]);
+      mf::d4 o;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int a = cw * mf::kB + 4 * v + (l >> 4), b = c0 + (l & 15);
-        o[v] = (x[w][v] + r[w][v]) * (pij[a] * pij[b]);
-        tr[(4 * v + (l >> 4)) * LDT + (l & 15)] = o[v];
+        o[v] = (xw[v] + r[w][v]) * (pij[a] * pij[b]);
       }
-      tv::lds_sync();
-#pragma unroll
-      for (int v = 0; v < 4; ++v) ot[v] = tr[(l & 15) * LDT + 4 * v + (l >> 4)];
-      tv::lds_sync();
+      const mf::d4 ot = transposed(o);
       if (cw == wave) {  // a diagonal tile: its lower triangle is what both halves get (the record holds nothing else)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -553,6 +572,23 @@ struct LaunchTeamDense {
 };
 #endif
 
+struct LaunchTeamSmoothPredict {
+  const SmoothParams& P;
+  double* ws;
+  hipStream_t s;
+  int rc = 0;
+  template <int d, int q>
+  void operator()() {
+    using W = MfmaSmoothWs<d, q + 1>;
+    constexpr size_t lds_bytes = ((size_t)W::D * (W::D + 1) / 2 + 2 * W::DP) * sizeof(double);  // the packed record, P m, m^s_+
+    static_assert(lds_bytes <= 160 * 1024, "the packed record does not fit the LDS");
+    if (hipFuncSetAttribute((const void*)rts_smooth_predict_kernel<d, q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+      rc = -6;
+      return;
+    }
+    hipLaunchKernelGGL((rts_smooth_predict_kernel<d, q>), dim3(team_grid(P.N)), dim3(predict_block<d>()), lds_bytes, s, P, ws);
+  }
+};
 struct LaunchTeamSmoothSweeps {
   const SmoothParams& P;
   double* ws;
@@ -562,7 +598,7 @@ struct LaunchTeamSmoothSweeps {
   void operator()() {
     using W = MfmaSmoothWs<d, q + 1>;
     // the factor (tile rows padded to 17 doubles) and its scratch; then M, the row buffer(s) of Z and delta (smooth_onchip.h)
-    constexpr size_t lds_factor = (size_t)(W::DPB * (W::DPB + 1) / 2) * mf::kB * 17 + 272, lds_products = (size_t)oc::Products<W::DPB>::size + 2 * W::DP;
+    constexpr size_t lds_factor = (size_t)(W::DPB * (W::DPB + 1) / 2) * mf::kB * 17 + 272, lds_products = (size_t)oc::Products<W::DPB>::size + 3 * W::DP;
     constexpr size_t lds_bytes = (lds_factor > lds_products ? lds_factor : lds_products) * sizeof(double);
     static_assert(lds_bytes <= 160 * 1024, "the on-chip record step does not fit the LDS");
     // (set at every launch: the attribute belongs to the current device, and a group of contexts spans several)
@@ -570,6 +606,7 @@ struct LaunchTeamSmoothSweeps {
       rc = -6;
       return;
     }
+    note_kernel("odef::rts_smooth_sweeps_kernel<%d, %d>", d, q);
     hipLaunchKernelGGL((rts_smooth_sweeps_kernel<d, q>), dim3(team_grid(P.N)), dim3(64 * W::DPB), lds_bytes, s, P, ws);
   }
 };
@@ -579,8 +616,8 @@ struct LaunchTeamSmooth {
   hipStream_t s;
   template <int d, int q>
   void operator()() {
-    // (the workspace kernel of the pass: the dominant one also when the sweeps run in a kernel of their own)
-    note_kernel(P.split_mode != 0 ? "odef::rts_smooth_mfma_kernel<%d, %d, true>" : "odef::rts_smooth_mfma_kernel<%d, %d, false>", d, q);
+    // (the split pass names its dominant kernel, rts_smooth_sweeps_kernel; this one only sets up its blocks)
+    if (P.split_mode == 0) note_kernel("odef::rts_smooth_mfma_kernel<%d, %d, false>", d, q);
     if (P.split_mode != 0)
       hipLaunchKernelGGL((rts_smooth_mfma_kernel<d, q, true>), dim3(team_grid(P.N)), dim3(kTeamBig), 0, s, P, ws);
     else

@@ -17,22 +17,20 @@ static int launch_filter_pleiades_tiles_order(int q, int ek1, const FilterParams
     default: return -2;
   }
 }
-int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles) {
-  return team_filter_staged<28>(q, ek1, P, s, adaptive, stage, stage_doubles, pleiades_filter_tiles(), launch_filter_pleiades_tiles_order);
+static int filter_pleiades(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles, long* staged_recs) {
+  return team_filter_staged<28>(q, ek1, P, s, adaptive, stage, stage_doubles, pleiades_filter_tiles(), launch_filter_pleiades_tiles_order, staged_recs);
 }
-int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s) { return team_smooth_inplace<28>(q, P, ws, s); }
-int launch_smooth_d28_staged(int q, const SmoothParams& P0, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s) {
-  return team_smooth_staged<28>(q, P0, n_rec, ws, stage, stage_doubles, s);
+static int smooth_pleiades(int q, const SmoothParams& P, double* ws, hipStream_t s) { return team_smooth_inplace<28>(q, P, ws, s); }
+static int smooth_pleiades_staged(int q, const SmoothParams& P0, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s,
+                                  long filter_recs_in_stage) {
+  return team_smooth_staged<28>(q, P0, n_rec, ws, stage, stage_doubles, s, filter_recs_in_stage);
 }
-int launch_dense_d28(int q, const DenseParams& P, double* ws, hipStream_t s) { return team_dense<28>(q, P, ws, s); }
-int launch_sample_d28(int q, const SampleParams& P, double* ws, hipStream_t s) { return team_sample<28>(q, P, ws, s); }
+static int dense_pleiades(int q, const DenseParams& P, double* ws, hipStream_t s) { return team_dense<28>(q, P, ws, s); }
+static int sample_pleiades(int q, const SampleParams& P, double* ws, hipStream_t s) { return team_sample<28>(q, P, ws, s); }
 long dense_d28_grid(long items) { return items < kDenseMfmaMaxGrid ? items : kDenseMfmaMaxGrid; }
 static size_t smooth_ws_pleiades(int q) { return team_smooth_ws<28>(q); }
-static int filter_pleiades(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles) {
-  return launch_filter_pleiades_tiles(q, ek1, P, s, adaptive, stage, stage_doubles);
-}
 const TeamLaunch* team_pleiades() {  // (a function-local table: a namespace-scope constant would also be emitted for the device)
-  static const TeamLaunch t = {28, filter_pleiades, launch_smooth_d28, launch_smooth_d28_staged, launch_dense_d28, launch_sample_d28, smooth_ws_pleiades};
+  static const TeamLaunch t = {28, filter_pleiades, smooth_pleiades, smooth_pleiades_staged, dense_pleiades, sample_pleiades, smooth_ws_pleiades};
   return &t;
 }
 }  // namespace odef

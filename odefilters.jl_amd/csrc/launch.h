@@ -33,9 +33,11 @@ int launch_sample_d3(int q, const SampleParams& P, hipStream_t s);
 struct TeamLaunch {
   int d;
   // fixed grid (adaptive = 0; every-step records through `stage` when all of them fit) or adaptive solve on the matrix-core filter
-  int (*filter)(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles);
+  // `staged_recs` (may be null): set to the number of records the kernel left in `stage` (trajectory-major, record r at r N ld), 0 if none
+  int (*filter)(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles, long* staged_recs);
   int (*smooth)(int q, const SmoothParams& P, double* ws, hipStream_t s);  // records in place
-  int (*smooth_staged)(int q, const SmoothParams& P, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s);
+  // `filter_recs_in_stage` == n_rec: the filter's records 0 .. n_rec - 1 are still in `stage` (nothing to copy in)
+  int (*smooth_staged)(int q, const SmoothParams& P, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s, long filter_recs_in_stage);
   int (*dense)(int q, const DenseParams& P, double* ws, hipStream_t s);    // ws: dense_d28_grid(items) x smooth_ws(q) doubles
   int (*sample)(int q, const SampleParams& P, double* ws, hipStream_t s);
   size_t (*smooth_ws)(int q);  // doubles of workspace per trajectory (smoother) / per grid slot (dense output, sampling)
@@ -43,12 +45,5 @@ struct TeamLaunch {
 const TeamLaunch* team_pleiades();  // d = 28 (BASELINE config 4)
 const TeamLaunch* team_lorenz96();  // d = 16: the same kernels on a second shape
 const TeamLaunch* team_launch(int rhs_id);  // nullptr: the field runs on the lane / row-team kernels
-// ... and Pleiades' own entry points (d = 28)
-int launch_filter_pleiades_tiles(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive = 0, double* stage = nullptr,
-                                 size_t stage_doubles = 0);  // register-tiled kernel (default)
-int launch_smooth_d28(int q, const SmoothParams& P, double* ws, hipStream_t s);
-int launch_smooth_d28_staged(int q, const SmoothParams& P, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s);
-int launch_dense_d28(int q, const DenseParams& P, double* ws, hipStream_t s);  // ws: dense_d28_grid(N n_q) x team_smooth_ws_doubles
-long dense_d28_grid(long items);
-int launch_sample_d28(int q, const SampleParams& P, double* ws, hipStream_t s);  // ws: dense_d28_grid(N n_samples) x team_smooth_ws_doubles
+long dense_d28_grid(long items);  // grid of the dense-output / sampling kernels (workspaces of smooth_ws(q) doubles)
 }  // namespace odef

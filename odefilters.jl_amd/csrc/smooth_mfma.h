@@ -47,8 +47,8 @@ struct MfmaSmoothWs {
   static constexpr int MSV = 7 * MAT;  // the carried smoothed mean between the launches of a staged pass
   // split pass (one kernel per phase): what the phases of a record hand over -- P m, delta, P^-1 (vectors) and the record
   // index the hand-over belongs to (-1: that record needs no algebra)
-  static constexpr int MFV = MSV + DP, DLV = MFV + DP, PIJV = DLV + DP, FLG = PIJV + DP;
-  static constexpr size_t size = (size_t)FLG + 8;
+  static constexpr int MFV = MSV + DP, DLV = MFV + DP, PIJV = DLV + DP, FLG = PIJV + DP, PJV = FLG + 8;  // (PJV: P)
+  static constexpr size_t size = (size_t)PJV + DP;
   // LDS (doubles): factorisation scratch, then the vectors
   static constexpr int kChol = mf::CholLds<DPB>::size;
   static constexpr int MF = kChol, MS = MF + DP, MP = MS + DP, DL = MP + DP, PJ = DL + DP, PIJ = PJ + DP;
@@ -390,14 +390,7 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
     __syncthreads();
     ODEF_STAMP(0);  // unpack
     mfma_predict_phase<d, q>(pc, sigma2, ws, lds);
-    if constexpr (SPLIT) {
-      // hand-over to part C (the factorisation and the sweeps run in rts_smooth_sweeps_kernel): P m, delta, P^-1
-      for (int k = tid; k < DP; k += nth) {
-        ws[W::MFV + k] = mf_[k];
-        ws[W::DLV + k] = dl_[k];
-        ws[W::PIJV + k] = pij_[k];
-      }
-    }
+    static_assert(!SPLIT, "the split pass unpacks and predicts in rts_smooth_predict_kernel (smooth_predict.h)");
     return true;
   };
   // part C: smoothed mean, the two products, pack and store
@@ -450,20 +443,10 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
     ODEF_STAMP(8);  // pack + store
     };
   if constexpr (SPLITK) {
-   if (P.split_mode == 2) {
-    // the hand-over flag: the record index part A prepared (-1: none, or a repeated save time)
-    const long prepared = (long)ws[W::FLG];
-    __syncthreads();
-    // (part C of the record the sweeps kernel has just been through -- smoothed mean, Sigma^s = X + G M G', the record in
-    // the stage and the carried SG -- was finished there, on chip)
-    (void)prepared;
-    bool active = false;
-    if (P.split_sa >= s_lo && P.split_sa <= s_hi) active = part_a(P.split_sa, std::true_type{});
-    __syncthreads();
-    if (tid == 0) ws[W::FLG] = active ? (double)P.split_sa : -1.0;
-   } else {
+    // the split pass: this launch only sets up / carries over the block's state (above); its records run as
+    // [rts_smooth_predict_kernel -> rts_smooth_sweeps_kernel] pairs, which hand over through the workspace (W::FLG: the
+    // record index the first one prepared, -1: none)
     if (tid == 0) ws[W::FLG] = -1.0;
-   }
   } else {
     for (long s = s_hi; s >= s_lo; --s) {
       if (!part_a(s, std::false_type{})) continue;

@@ -24,8 +24,9 @@ inline void launch_stage_copy(bool in, const double* src, double* dst, long N, l
 // `by_order(q, ek1, P, s, adaptive)`: the field's filter launcher for one order.
 template <int d, class ByOrder>
 int team_filter_staged(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles,
-                       bool valu_kernel_selected, ByOrder&& by_order) {
+                       bool valu_kernel_selected, ByOrder&& by_order, long* staged_recs) {
   const long D = (long)d * (q + 1), TRI = D * (D + 1) / 2, ld = stage_record_ld(TRI), n_rec = P.nsteps + 1;
+  if (staged_recs) *staged_recs = 0;
   if (adaptive || !P.everystep || valu_kernel_selected || !stage || (size_t)n_rec * (size_t)P.N * (size_t)ld > stage_doubles)
     return by_order(q, ek1, P, s, adaptive);
   FilterParams PS = P;
@@ -34,6 +35,7 @@ int team_filter_staged(int q, int ek1, const FilterParams& P, hipStream_t s, int
   const int rc = by_order(q, ek1, PS, s, 0);
   if (rc) return rc;
   launch_stage_copy(false, stage, P.cov, P.N, TRI, ld, n_rec, s);
+  if (staged_recs) *staged_recs = n_rec;  // (the stage keeps them: a smoother pass that follows need not copy them in again)
   return 0;
 }
 
@@ -41,13 +43,17 @@ int team_filter_staged(int q, int ek1, const FilterParams& P, hipStream_t s, int
 // `stage` holds, from the last record down: [records in] -> smoother launch over the block (carried state in the workspace)
 // -> [records out].  `n_rec`: number of save slots in use (fixed grids: n_save; adaptive: the largest nsaved of the
 // ensemble -- every trajectory joins in at the block that holds its own last record).  stage_doubles must hold at
-// least two records.
+// least two records.  filter_recs_in_stage == n_rec: the filter has left all its records in `stage` (team_filter_staged; record r
+// at r N ld, stage_doubles counted from record 1) -- the pass then runs as one block on them, nothing is copied in.
 template <int d>
-int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s) {
+int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s,
+                       long filter_recs_in_stage) {
   const long n = n_rec, N = P0.N;
   const long D = (long)d * (q + 1), TRI = D * (D + 1) / 2, ld = stage_record_ld(TRI);
   const size_t per_rec = (size_t)N * (size_t)ld;
   const long cap = (long)(stage_doubles / per_rec);
+  const bool resident = filter_recs_in_stage == n && cap >= n - 1;
+  if (resident) stage += per_rec;  // (the block starts at record 1)
   if (n < 2 || n > P0.n_save || cap < 2) return -4;  // the caller runs the pass on the records in place
   // record 0 is never smoothed (src/smoothing.jl:11) and never staged: copied here (a trajectory that has no other record
   // is not visited by any launch)
@@ -61,7 +67,7 @@ int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, do
     P.stage_s0 = lo;
     P.stage_hi = hi;
     P.stage_ld = ld;
-    launch_stage_copy(true, P0.cov + (size_t)lo * TRI * N, stage, N, TRI, ld, hi - lo + 1, s);
+    if (!resident) launch_stage_copy(true, P0.cov + (size_t)lo * TRI * N, stage, N, TRI, ld, hi - lo + 1, s);
     if (!pleiades_smooth_split()) {
       LaunchTeamSmooth f{P, ws, s};
       const int rc = dispatch_smooth_order<d>(q, f);
@@ -83,9 +89,9 @@ int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, do
         P.split_sc = -1;
         P.split_sa = r;
         {
-          LaunchTeamSmooth f{P, ws, s};
+          LaunchTeamSmoothPredict f{P, ws, s};
           const int rc = dispatch_smooth_order<d>(q, f);
-          if (rc) return rc;
+          if (rc || f.rc) return rc ? rc : f.rc;
         }
         LaunchTeamSmoothSweeps g{P, ws, s};
         const int rc = dispatch_smooth_order<d>(q, g);

@@ -429,7 +429,8 @@ def test_lorenz96_on_the_matrix_core_kernels(pkg, q, kind, smoother, monkeypatch
     ens = pkg.EnsembleProblem(pkg.ODEProblem("lorenz96", vf.u0, (0.0, ns * dt), vf.p), perturb_scale=1e-2)
     sol = pkg.solve(ens, _alg(pkg, kind, q), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
     assert sol.retcode == ["Success"] * N
-    assert "ek_filter_mfma_kernel<odef::RhsLorenz96" in sol.ctx.kernel_name(0) and "rts_smooth_mfma_kernel<16" in sol.ctx.kernel_name(1)
+    assert "ek_filter_mfma_kernel<odef::RhsLorenz96" in sol.ctx.kernel_name(0)
+    assert ("rts_smooth_sweeps_kernel<16" if smoother == "split" else "rts_smooth_mfma_kernel<16") in sol.ctx.kernel_name(1)
     u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
     np.testing.assert_array_equal(sol.ctx.get(13).T, u0s)
     alg_o = orc.Alg(kind, q, "dynamic", True)
