@@ -20,7 +20,13 @@ namespace odef {
 
 template <int d>
 constexpr int predict_block() {
-  return d * d >= 1024 ? 1024 : (d * d + 63) / 64 * 64;
+#ifdef ODEF_PREDICT_BLOCK  // (A/B builds of tools/split_smooth_stamps.hip)
+  return ODEF_PREDICT_BLOCK;
+#else
+  // at most two wavefronts per SIMD: a pair's (q+1) x (q+1) block and its results want ~200 registers at q = 5 (with 13
+  // wavefronts -- one round over the 784 pairs of d = 28, 128 registers -- 276 bytes per lane spill: 0.59 against 0.47 ms)
+  return d * d >= 512 ? 512 : (d * d + 63) / 64 * 64;
+#endif
 }
 
 template <int d, int q>

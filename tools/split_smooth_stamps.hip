@@ -1,7 +1,7 @@
 // Where does a record of the D = 168 smoother's split pass spend its time?  Diagnostic build with wall-clock stamps at the
 // phase boundaries of workgroup 0 of the on-chip kernel (rts_smooth_sweeps_kernel, csrc/ek_kernels.h), run on a synthetic
 // set of staged filter records (random SPD covariances of Pleiades size) with N trajectories, and the time per launch of
-// both kernels of the pass.
+// both kernels of the pass (rts_smooth_predict_kernel, rts_smooth_sweeps_kernel).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -DODEF_SWEEPS_STAMPS -I odefilters.jl_amd/csrc tools/split_smooth_stamps.hip -o tools/_bin/split_smooth_stamps
 #include "ek_kernels.h"
 #include <cstdio>
@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
     for (long r = ns - 2; r >= 1; --r) {
       P.split_sa = r;
       (void)hipEventRecord(ev[ne++], s);
-      { LaunchTeamSmooth f{P, (double*)ws, s}; f.operator()<d, q>(); }
+      { LaunchTeamSmoothPredict f{P, (double*)ws, s}; f.operator()<d, q>(); if (f.rc) { printf("launch failed\n"); return 1; } }
       (void)hipEventRecord(ev[ne++], s);
       LaunchTeamSmoothSweeps g{P, (double*)ws, s};
       g.operator()<d, q>();
