@@ -260,11 +260,13 @@ __device__ unsigned long long g_sweeps_t0;
 #else
 #define ODEF_SSTAMP(k)
 #endif
-// The Cholesky factorisation and the two block sweeps of ONE record for every trajectory, on chip (split pass, the default of
-// the staged smoother; prototype and measurements of the sweeps: tools/onchip_sweep_proto.hip): one workgroup of DPB
-// wavefronts per trajectory, the upper tiles of B in LDS (rows padded to 17 doubles so that the transposed reads of the
-// backward sweep are bank-conflict free), factorised there; then wavefront c holds tile column c of the right-hand sides
-// in its accumulators for both sweeps -- no barrier, no re-read, the factor never leaves the chip.
+// ONE record of the smoother for every trajectory, on chip (split pass, the default of the staged smoother; behind
+// rts_smooth_predict_kernel, which leaves B, Y' = A X, M and the vectors in the workspace): one workgroup of DPB wavefronts per
+// trajectory.  The upper tiles of B go to LDS (rows padded to 17 doubles so that the transposed reads of the backward sweep are
+// bank-conflict free) and are factorised there; wavefront c holds tile column c of the right-hand sides in its accumulators
+// for both sweeps -- no barrier, no re-read, the factor never leaves the chip -- and keeps G' there for the mean, for
+// R = G M G' (smooth_onchip.h) and for the smoothed record.  Prototypes and measurements: tools/onchip_sweep_proto.hip,
+// tools/onchip_products_proto.hip; phase stamps: tools/split_smooth_stamps.hip.
 template <int d, int q>
 __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth_sweeps_kernel(const SmoothParams P, double* ws) {
   using W = MfmaSmoothWs<d, q + 1>;
