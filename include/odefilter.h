@@ -154,13 +154,18 @@ const char* odef_last_error(const odef_ctx* ctx); /* ctx may be NULL: last error
  *     };
  *
  * A hipcc child process ($ODEFILTER_HIP_HIPCC, else hipcc on PATH, else /opt/rocm/bin/hipcc) compiles the library's
- * own kernels around it for gfx950 -- one lane per trajectory, and for d(q+1) <= 16 also the 16-lanes-per-trajectory kernels
- * that small and sharded ensembles use, chosen by ensemble size exactly as for the compiled-in fields -- (include_dir =
- * directory holding the csrc headers; NULL: $ODEFILTER_HIP_INCLUDE, else ../csrc next to the loaded library, else the
- * build-time location).  Returns 0 and a new rhs id (>= 100) for
- * odef_config.rhs_id; on a compile error returns -1 and odef_last_error(NULL) holds the compiler log.
- * Filter and smoother: d <= 10 and d(q+1) <= 20; dense output and sampling: d(q+1) <= 12.  Whatever the compiler
- * rejects comes back as an error with its log. */
+ * own kernels around it for gfx950 (include_dir = directory holding the csrc headers; NULL: $ODEFILTER_HIP_INCLUDE, else
+ * ../csrc next to the loaded library, else the build-time location):
+ *   d(q+1) <= 20, d <= 10   one lane per trajectory, and for d(q+1) <= 16 also the 16-lanes-per-trajectory kernels that small
+ *                           and sharded ensembles use, chosen by ensemble size exactly as for the compiled-in fields
+ *                           (dense output and sampling: d(q+1) <= 12 on lanes, <= 32 on row teams);
+ *   above, even d <= 32,    the workgroup-per-trajectory kernels on the matrix cores (filter on fixed grids and adaptive,
+ *   d(q+1) <= 176           smoother, dense output, sampling) -- built at odef_create for that order and algorithm as a host +
+ *                           device shared object that links against this library (tens of seconds to minutes).
+ * Returns 0 and a new rhs id (>= 100) for odef_config.rhs_id; on a compile error returns -1 and odef_last_error(NULL) holds
+ * the compiler log (d <= 10: the order-1 lane filter is built at once; above: a probe kernel that evaluates f in double, in
+ * forward mode and on Taylor jets).  An odd d above state dimension 20 has no kernel: odef_create says so.  Whatever the
+ * compiler rejects comes back as an error with its log. */
 int odef_rhs_compile(const char* name, const char* source, int32_t d, int32_t n_params, const char* include_dir,
                      int32_t* rhs_id);
 

@@ -320,8 +320,11 @@ int odef_create(odef_ctx** out, const odef_config* cfg) {
   if (cfg->diffusion != ODEF_DIFFUSION_DYNAMIC && cfg->diffusion != ODEF_DIFFUSION_FIXED && cfg->diffusion != ODEF_DIFFUSION_FIXED_MAP)
     return fail(nullptr, "odef_create: unknown diffusion model %d", cfg->diffusion);
   if (cfg->n_traj <= 0) return fail(nullptr, "odef_create: n_traj must be positive");
-  if (cfg->rhs_id >= kJitFirstId && cfg->d * (cfg->order + 1) > 20)
-    return fail(nullptr, "odef_create: run-time compiled vector fields use the lane-per-trajectory kernels, state dimension d(q+1) <= 20 (got %d)", cfg->d * (cfg->order + 1));
+  // run-time compiled fields: lane / row-team kernels up to state dimension 20 (d <= 10), the workgroup-per-trajectory kernels above
+  const bool jit_team = cfg->rhs_id >= kJitFirstId && (cfg->d * (cfg->order + 1) > 20 || cfg->d > 10);
+  if (jit_team && (cfg->d % 2 != 0 || cfg->d > 32 || cfg->d * (cfg->order + 1) > 176))
+    return fail(nullptr, "odef_create: run-time compiled vector fields above state dimension 20 run on the workgroup-per-trajectory kernels: even d <= 32 and d(q+1) <= 176 (got d = %d, d(q+1) = %d)",
+                cfg->d, cfg->d * (cfg->order + 1));
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, "odef_create: no HIP device available (libodefilter_hip has no CPU path)");
@@ -340,7 +343,16 @@ int odef_create(odef_ctx** out, const odef_config* cfg) {
   c->team = team_launch(cfg->rhs_id);
   c->team_path = c->team != nullptr;
   hipError_t e = hipSetDevice(c->device);
-  if (e == hipSuccess && cfg->rhs_id >= kJitFirstId) {
+  if (e == hipSuccess && jit_team) {
+    std::string jerr;
+    c->team = jit_get_team(cfg->rhs_id, c->q, cfg->alg == ODEF_EK1, jerr);
+    c->team_path = c->team != nullptr;
+    if (!c->team) {
+      g_create_error = "odef_create: " + jerr;  // the whole compiler log
+      delete c;
+      return -1;
+    }
+  } else if (e == hipSuccess && cfg->rhs_id >= kJitFirstId) {
     std::string jerr;
     c->jit = jit_get_module(cfg->rhs_id, c->q, cfg->alg == ODEF_EK1, c->device, jerr);
     if (!c->jit) {

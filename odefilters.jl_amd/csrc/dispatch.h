@@ -21,8 +21,14 @@ inline int dispatch_order(int q, int ek1, F&& f) {
     default: return -2;
   }
 }
-template <int d, class F>
+// ONLYQ != 0: a translation unit built for one order (run-time compiled fields, jit.hip) instantiates that order alone
+template <int d, int ONLYQ = 0, class F>
 inline int dispatch_smooth_order(int q, F&& f) {
+  if constexpr (ONLYQ != 0) {
+    if (q != ONLYQ) return -2;
+    f.template operator()<d, ONLYQ>();
+    return 0;
+  } else
   switch (q) {
     case 1: f.template operator()<d, 1>(); return 0;
     case 2: f.template operator()<d, 2>(); return 0;

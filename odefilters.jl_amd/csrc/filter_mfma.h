@@ -579,7 +579,7 @@ struct MfmaFilter {
         for (int a = 0; a < d; ++a) u_[a] = up[a];
         RHS::f(u_, p, du_);
         for (int a = 0; a < d; ++a) du[a] = du_[a];
-        if constexpr (IS_EK1) RHS::jac(u_, p, *reinterpret_cast<double (*)[d][d]>(H0));
+        if constexpr (IS_EK1) rhs_jacobian<RHS>(u_, p, *reinterpret_cast<double (*)[d][d]>(H0));  // (its own jac, else forward mode)
       }
     }
     tv::lds_sync();

@@ -43,6 +43,14 @@ struct JitRhs {
 std::mutex g_mu;
 std::vector<JitRhs> g_rhs;                                                      // id = kJitFirstId + index
 std::map<std::tuple<int, int, int, int>, std::unique_ptr<JitModule>> g_modules;  // (id, q, ek1, device)
+std::map<std::tuple<int, int, int>, const TeamLaunch*> g_teams;                  // (id, q, ek1): shared objects, never unloaded
+
+// path of this library (the run-time compiled shared objects of the workgroup-per-trajectory path link against it)
+std::string this_library() {
+  Dl_info info;
+  if (dladdr((const void*)&this_library, &info) && info.dli_fname) return info.dli_fname;
+  return std::string();
+}
 
 // Where the kernel headers live: $ODEFILTER_HIP_INCLUDE, else `../csrc` next to the directory this library was loaded
 // from (odefilters.jl_amd/lib/libodefilter_hip.so -> odefilters.jl_amd/csrc; found with dladdr, so a tree that was moved
@@ -157,6 +165,62 @@ std::string translation_unit(const JitRhs& r, int q, int ek1, bool with_posterio
   return s;
 }
 
+// The workgroup-per-trajectory path (state dimension above 20, even d <= 32): the matrix-core filter (fixed grids and
+// adaptive), the smoother (persistent and split pass), dense output and sampling of filter_mfma.h / smooth_mfma.h /
+// dense_mfma.h / sample_mfma.h around the user's field, for ONE order and ONE algorithm, with their host-side launch code
+// (team_launch_impl.h) -- exactly what inst_lorenz96.hip is for a compiled-in field.  The module exports the function table
+// the C-ABI layer launches through.
+std::string team_translation_unit(const JitRhs& r, int q, int ek1) {
+  const std::string Q = std::to_string(q), EK = ek1 ? "true" : "false", DD = std::to_string(r.d);
+  std::string s = "#include \"team_launch_impl.h\"\nnamespace odef {\n";
+  s += r.source;
+  s += "\nstruct RhsJit : " + r.name + " { static constexpr const char* name = \"" + r.name + "\"; };\n";
+  s += "static_assert(RhsJit::d == " + DD + ", \"d of the struct differs from the d passed to odef_rhs_compile\");\n";
+  s += "static_assert(RhsJit::np == " + std::to_string(r.np) + ", \"np of the struct differs from the n_params passed to odef_rhs_compile\");\n";
+  s += "static int jit_filter_order(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive) {\n"
+       "  if (q != " + Q + " || (ek1 != 0) != " + EK + ") return -2;\n"
+       "  LaunchTilesFilterT<false> f{P, s, adaptive};\n"
+       "  f.template operator()<RhsJit, " + Q + ", " + EK + ">();\n"
+       "  return 0;\n}\n";
+  s += "static int jit_filter(int q, int ek1, const FilterParams& P, hipStream_t s, int adaptive, double* stage, size_t stage_doubles, long* staged_recs) {\n"
+       "  return team_filter_staged<" + DD + ">(q, ek1, P, s, adaptive, stage, stage_doubles, false, jit_filter_order, staged_recs);\n}\n";
+  s += "static int jit_smooth(int q, const SmoothParams& P, double* ws, hipStream_t s) { return team_smooth_inplace<" + DD + ", " + Q + ">(q, P, ws, s); }\n";
+  s += "static int jit_smooth_staged(int q, const SmoothParams& P, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s, long in_stage) {\n"
+       "  return team_smooth_staged<" + DD + ", " + Q + ">(q, P, n_rec, ws, stage, stage_doubles, s, in_stage);\n}\n";
+  s += "static int jit_dense(int q, const DenseParams& P, double* ws, hipStream_t s) { return team_dense<" + DD + ", " + Q + ">(q, P, ws, s); }\n";
+  s += "static int jit_sample(int q, const SampleParams& P, double* ws, hipStream_t s) { return team_sample<" + DD + ", " + Q + ">(q, P, ws, s); }\n";
+  s += "static size_t jit_smooth_ws(int q) { return team_smooth_ws<" + DD + ", " + Q + ">(q); }\n";
+  s += "}  // namespace odef\n";
+  s += "extern \"C\" const odef::TeamLaunch* odef_jit_team() {\n"
+       "  using namespace odef;\n"
+       "  static const TeamLaunch t = {" + DD + ", jit_filter, jit_smooth, jit_smooth_staged, jit_dense, jit_sample, jit_smooth_ws};\n"
+       "  return &t;\n}\n";
+  return s;
+}
+
+// What odef_rhs_compile builds for d > 10 (no lane kernel exists to try the text on): the vector field in double, in
+// forward mode (the Jacobian EK1 needs when the struct has none) and on Taylor jets (the initialisation)
+std::string probe_translation_unit(const JitRhs& r) {
+  const std::string DD = std::to_string(r.d);
+  std::string s = "#include \"ek_lane.h\"\nnamespace odef {\n";
+  s += r.source;
+  s += "\nusing RhsJit = " + r.name + ";\n";
+  s += "static_assert(RhsJit::d == " + DD + ", \"d of the struct differs from the d passed to odef_rhs_compile\");\n";
+  s += "static_assert(RhsJit::np == " + std::to_string(r.np) + ", \"np of the struct differs from the n_params passed to odef_rhs_compile\");\n";
+  s += "extern \"C\" __global__ void odef_jit_probe(const double* u, const double* p, double* out) {\n"
+       "  constexpr int d = " + DD + ";\n"
+       "  double uu[d], du[d], J[d][d], m0[2 * d];\n"
+       "  for (int a = 0; a < d; ++a) uu[a] = u[a];\n"
+       "  RhsJit::f(uu, p, du);\n"
+       "  rhs_jacobian<RhsJit>(uu, p, J);\n"
+       "  taylor_init<RhsJit, 1>(uu, p, m0);\n"
+       "  double acc = 0.0;\n"
+       "  for (int a = 0; a < d; ++a) acc += du[a] + J[a][a] + m0[d + a];\n"
+       "  out[0] = acc;\n}\n";
+  s += "}  // namespace odef\n";
+  return s;
+}
+
 // Source -> gfx950 code object; on failure `err` holds the compiler log.
 // The compiler runs as a CHILD PROCESS (hipcc --genco), not in-process through hiprtc: hiprtc/comgr of ROCm 7.2 aborts
 // the whole host process ("LLVM ERROR: Unsupported instruction") on the larger lane kernels (state dimension 14 and
@@ -262,14 +326,24 @@ void remove_tree(const std::string& dir) {  // the compiler's temporaries (flat 
 }
 
 // `agpr_first_slot` >= 0: the translation unit holds the lane smoother, whose AGPR file starts at that register (see above)
-bool compile(const std::string& src, const std::string& include_dir, std::vector<char>& code, std::string& err, int agpr_first_slot = -1) {
+// shared_out != nullptr: build a host + device SHARED OBJECT instead of a code object (the workgroup-per-trajectory path: its
+// host-side launch code, team_launch_impl.h, is compiled around the user's field too); *shared_out receives a handle from dlopen
+bool compile(const std::string& src, const std::string& include_dir, std::vector<char>& code, std::string& err, int agpr_first_slot = -1,
+             void** shared_out = nullptr) {
   char tmpl[] = "/tmp/odef_jit_XXXXXX";
   const char* dir = mkdtemp(tmpl);
   if (!dir) {
     err = "odef_rhs_compile: cannot create a temporary directory under /tmp";
     return false;
   }
-  const std::string base = dir, srcp = base + "/rhs.hip", outp = base + "/rhs.co", logp = base + "/log.txt";
+  const std::string base = dir, srcp = base + "/rhs.hip", outp = base + (shared_out ? "/rhs.so" : "/rhs.co"), logp = base + "/log.txt";
+  // (handed to the linker with -Wl: hipcc would take a bare path for another HIP source)
+  const std::string self_path = shared_out ? this_library() : std::string(), self = "-Wl," + self_path;
+  if (shared_out && self_path.empty()) {
+    err = "odef_rhs_compile: cannot locate libodefilter_hip.so (dladdr) to link the run-time compiled module against";
+    remove_tree(base);
+    return false;
+  }
   {
     FILE* f = fopen(srcp.c_str(), "wb");
     const bool written = f && fwrite(src.data(), 1, src.size(), f) == src.size();
@@ -291,8 +365,13 @@ bool compile(const std::string& src, const std::string& include_dir, std::vector
     posix_spawn_file_actions_addopen(&fa, 1, logp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
     posix_spawn_file_actions_adddup2(&fa, 1, 2);
     // (--save-temps=obj: the ISA listing lands next to the output, for agpr_file_violation)
-    const char* argv[] = {cc, "--offload-arch=gfx950", "-O3", "-std=c++20", "--genco", "-fno-crash-diagnostics", agpr_first_slot >= 0 ? "--save-temps=obj" : "-DODEF_NO_LISTING",
-                          inc.c_str(), srcp.c_str(), "-o", outp.c_str(), nullptr};
+    const char* argv_co[] = {cc, "--offload-arch=gfx950", "-O3", "-std=c++20", "--genco", "-fno-crash-diagnostics", agpr_first_slot >= 0 ? "--save-temps=obj" : "-DODEF_NO_LISTING",
+                             inc.c_str(), srcp.c_str(), "-o", outp.c_str(), nullptr};
+    // (-amdgpu-function-calls=false: every device function inline -- kernels with different register budgets must not
+    // share an out-of-line callee, see out_of_line_device_functions)
+    const char* argv_so[] = {cc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared", "-fno-crash-diagnostics", "-mllvm", "-amdgpu-function-calls=false",
+                             inc.c_str(), srcp.c_str(), "-o", outp.c_str(), self.c_str(), nullptr};
+    const char* const* argv = shared_out ? argv_so : argv_co;
     pid_t pid = 0;
     const int rc = posix_spawnp(&pid, cc, &fa, nullptr, const_cast<char* const*>(argv), environ);
     posix_spawn_file_actions_destroy(&fa);
@@ -307,6 +386,18 @@ bool compile(const std::string& src, const std::string& include_dir, std::vector
     break;
   }
   bool ok = spawned && WIFEXITED(status) && WEXITSTATUS(status) == 0;
+  if (ok && shared_out) {
+    // (the mapping outlives the file: the temporary directory goes away below)
+    *shared_out = dlopen(outp.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!*shared_out) {
+      const char* de = dlerror();
+      err = std::string("odef_rhs_compile: dlopen of the run-time compiled module failed: ") + (de ? de : "?");
+      remove_tree(base);
+      return false;
+    }
+    remove_tree(base);
+    return true;
+  }
   if (ok) {
     const std::string co = read_file(outp);
     ok = !co.empty();
@@ -350,14 +441,14 @@ int jit_register(const char* name, const char* source, int d, int np, const char
     err = "odef_rhs_compile: null or empty name/source";
     return -1;
   }
-  if (d < 1 || d > 10 || np < 0) {
-    err = "odef_rhs_compile: d must be in 1..10 (the lane kernels handle d(q+1) <= 20) and n_params >= 0";
+  if (d < 1 || d > 32 || np < 0) {
+    err = "odef_rhs_compile: d must be in 1..32 (lane kernels: d(q+1) <= 20; above that the workgroup-per-trajectory kernels, even d) and n_params >= 0";
     return -1;
   }
   JitRhs r{name, source, include_dir ? include_dir : "", d, np};
-  // compile the order-1 filter once now so that errors in the user's text surface here, with the compiler log
+  // compile the order-1 filter (d <= 10; a probe kernel above) once now so that errors in the user's text surface here, with the compiler log
   std::vector<char> code;
-  if (!compile(translation_unit(r, 1, 1, false), r.include_dir, code, err)) return -1;
+  if (!compile(d <= 10 ? translation_unit(r, 1, 1, false) : probe_translation_unit(r), r.include_dir, code, err)) return -1;
   std::lock_guard<std::mutex> lk(g_mu);
   g_rhs.push_back(std::move(r));
   return kJitFirstId + (int)g_rhs.size() - 1;
@@ -432,6 +523,38 @@ JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& e
   JitModule* out = m.get();
   g_modules[key] = std::move(m);
   return out;
+}
+
+const TeamLaunch* jit_get_team(int rhs_id, int q, int ek1, std::string& err) {
+  // as jit_get_module: the compiler (minutes for these kernels) runs outside the registry lock
+  const auto key = std::make_tuple(rhs_id, q, ek1);
+  JitRhs r;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int k = rhs_id - kJitFirstId;
+    if (k < 0 || k >= (int)g_rhs.size()) {
+      err = "unknown run-time rhs id";
+      return nullptr;
+    }
+    auto it = g_teams.find(key);
+    if (it != g_teams.end()) return it->second;
+    r = g_rhs[k];
+  }
+  std::vector<char> unused;
+  void* handle = nullptr;
+  if (!compile(team_translation_unit(r, q, ek1), r.include_dir, unused, err, -1, &handle)) return nullptr;
+  using Entry = const TeamLaunch* (*)();
+  Entry entry = (Entry)dlsym(handle, "odef_jit_team");
+  if (!entry) {
+    err = "odef_jit_team missing from the run-time compiled module";
+    return nullptr;
+  }
+  const TeamLaunch* t = entry();
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_teams.find(key);
+  if (it != g_teams.end()) return it->second;  // (somebody else published it meanwhile; the duplicate module stays loaded, unused)
+  g_teams[key] = t;
+  return t;
 }
 
 int jit_launch(hipFunction_t f, unsigned gx, unsigned gy, const void* params, hipStream_t s, unsigned block) {

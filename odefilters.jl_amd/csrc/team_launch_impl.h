@@ -45,7 +45,7 @@ int team_filter_staged(int q, int ek1, const FilterParams& P, hipStream_t s, int
 // ensemble -- every trajectory joins in at the block that holds its own last record).  stage_doubles must hold at
 // least two records.  filter_recs_in_stage == n_rec: the filter has left all its records in `stage` (team_filter_staged; record r
 // at r N ld, stage_doubles counted from record 1) -- the pass then runs as one block on them, nothing is copied in.
-template <int d>
+template <int d, int ONLYQ = 0>
 int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s,
                        long filter_recs_in_stage) {
   const long n = n_rec, N = P0.N;
@@ -70,7 +70,7 @@ int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, do
     if (!resident) launch_stage_copy(true, P0.cov + (size_t)lo * TRI * N, stage, N, TRI, ld, hi - lo + 1, s);
     if (!pleiades_smooth_split()) {
       LaunchTeamSmooth f{P, ws, s};
-      const int rc = dispatch_smooth_order<d>(q, f);
+      const int rc = dispatch_smooth_order<d, ONLYQ>(q, f);
       if (rc) return rc;
     } else {
       // one kernel per phase and record: [set up the block] then, record by record from the top,
@@ -80,7 +80,7 @@ int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, do
       P.split_sc = P.split_sa = -1;
       {
         LaunchTeamSmooth f{P, ws, s};
-        const int rc = dispatch_smooth_order<d>(q, f);
+        const int rc = dispatch_smooth_order<d, ONLYQ>(q, f);
         if (rc) return rc;
       }
       const long r_hi = hi < n - 2 ? hi : n - 2, r_lo = lo;
@@ -90,11 +90,11 @@ int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, do
         P.split_sa = r;
         {
           LaunchTeamSmoothPredict f{P, ws, s};
-          const int rc = dispatch_smooth_order<d>(q, f);
+          const int rc = dispatch_smooth_order<d, ONLYQ>(q, f);
           if (rc || f.rc) return rc ? rc : f.rc;
         }
         LaunchTeamSmoothSweeps g{P, ws, s};
-        const int rc = dispatch_smooth_order<d>(q, g);
+        const int rc = dispatch_smooth_order<d, ONLYQ>(q, g);
         if (rc || g.rc) return rc ? rc : g.rc;
       }
     }
@@ -104,23 +104,25 @@ int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, do
   return 0;
 }
 
-template <int d>
+template <int d, int ONLYQ = 0>
 int team_smooth_inplace(int q, const SmoothParams& P, double* ws, hipStream_t s) {
   LaunchTeamSmooth f{P, ws, s};
-  return dispatch_smooth_order<d>(q, f);
+  return dispatch_smooth_order<d, ONLYQ>(q, f);
 }
-template <int d>
+template <int d, int ONLYQ = 0>
 int team_dense(int q, const DenseParams& P, double* ws, hipStream_t s) {
   LaunchTeamDense f{P, ws, s};
-  return dispatch_smooth_order<d>(q, f);
+  return dispatch_smooth_order<d, ONLYQ>(q, f);
 }
-template <int d>
+template <int d, int ONLYQ = 0>
 int team_sample(int q, const SampleParams& P, double* ws, hipStream_t s) {
   LaunchTeamSample f{P, ws, s};
-  return dispatch_smooth_order<d>(q, f);
+  return dispatch_smooth_order<d, ONLYQ>(q, f);
 }
-template <int d>
+template <int d, int ONLYQ = 0>
 size_t team_smooth_ws(int q) {
+  if constexpr (ONLYQ != 0) return q == ONLYQ ? MfmaSmoothWs<d, ONLYQ + 1>::size : 0;
+  else
   switch (q) {
     case 1: return MfmaSmoothWs<d, 2>::size;
     case 2: return MfmaSmoothWs<d, 3>::size;

@@ -1186,6 +1186,66 @@ def test_user_vector_field_larger_state(pkg, d, q):
     np.testing.assert_array_equal(sol.sample_states(3, 7), s1)
 
 
+def test_user_vector_field_on_the_matrix_core_kernels(pkg):
+    """A user vector field ABOVE state dimension 20: Lorenz-96 with 12 variables at order 2 (D = 36; no compiled-in field has
+    d = 12, and the struct has no `jac`).  odef_rhs_compile builds the workgroup-per-trajectory kernels of csrc/filter_mfma.h /
+    smooth_mfma.h / dense_mfma.h around it for this one order and algorithm -- with their host-side launch code, as a shared
+    object that exports the launch table (csrc/jit.hip, team_translation_unit) -- and the context runs on it like on a
+    compiled-in field: fixed grid filter (forward-mode Jacobian on one lane of the helper wavefront) + split-pass smoother
+    against the oracle at the oracle's rounding-noise level, the adaptive filter against the oracle's controller loop, sol(t)."""
+    d, q, name = 12, 2, "UserL96d12"
+    pkg.compile_rhs(name, _l96_source(name, d), d, 1)
+
+    def f(u, p, t):
+        return [(u[(i + 1) % d] - u[(i + d - 2) % d]) * u[(i + d - 1) % d] - u[i] + p[0] for i in range(d)]
+
+    def jac(u, p, t):
+        J = np.zeros((d, d))
+        for i in range(d):
+            ip, im2, im1 = (i + 1) % d, (i + d - 2) % d, (i + d - 1) % d
+            J[i, ip] += u[im1]
+            J[i, im2] -= u[im1]
+            J[i, im1] += u[ip] - u[im2]
+            J[i, i] -= 1.0
+        return J
+
+    u0 = np.array([1.0, 2.0, 0.5, -1.0, 0.3, 1.5, -0.7, 0.9, 1.2, -0.4, 0.8, 2.1])
+    vf = orc.VectorField(name, 100, d, 1, f, jac, u0, np.array([8.0]), (0.0, 0.1))
+    N, ns, dt = 3, 12, 2.0**-7
+    ens = pkg.EnsembleProblem(pkg.ODEProblem(name, vf.u0, (0.0, ns * dt), vf.p), perturb_scale=1e-2)
+    sol = pkg.solve(ens, pkg.EK1(order=q), pkg.EnsembleHIP(), trajectories=N, dt=dt, adaptive=False)
+    assert sol.retcode == ["Success"] * N
+    assert f"ek_filter_mfma_kernel<odef::{name}" in sol.ctx.kernel_name(0) and "rts_smooth_sweeps_kernel<12" in sol.ctx.kernel_name(1)
+    u0s = orc.ensemble_u0(vf.u0, N, 1e-2)
+    alg_o = orc.Alg("EK1", q, "dynamic", True)
+    mf, ms, cf, cs = sol.x_filt_mean(), sol.x_smooth_mean(), sol.x_filt_cov(), sol.x_smooth_cov()
+    for i in (0, 2):
+        for smoothed, m, c in ((False, mf, cf), (True, ms, cs)):
+            base, nm, nc = P.oracle_noise(vf, alg_o, u0s[i], dict(tspan=(0.0, ns * dt), dt=dt), smoothed)
+            P.check_against_oracle(m[i], c[i], base.means(smoothed=smoothed), base.covs(smoothed=smoothed), d, nm, nc,
+                                   f"user L96 d=12 traj {i} smoothed={smoothed}")
+    # sol(t) (csrc/dense_mfma.h), smoothed posterior
+    consts = orc.make_consts(d, q)
+    ref = orc.solve(vf, orc.EK1(order=q), u0=u0s[0], tspan=(0.0, ns * dt), dt=dt)
+    tq = np.array([0.013, 2.0**-7 * 5, ns * dt])
+    qm, _ = sol(tq)
+    want = np.array([orc.dense_output(ref, consts, float(t), smoothed=True).mu[:d] for t in tq])
+    np.testing.assert_allclose(qm[0][:, :d], want, rtol=1e-8, atol=1e-11)
+    # the adaptive filter of the same module
+    sol = pkg.solve(pkg.ODEProblem(name, vf.u0, vf.tspan, vf.p), pkg.EK1(order=q, smooth=False), dt=2.0**-8, adaptive=True, abstol=1e-7, reltol=1e-5,
+                    max_steps=256)
+    assert sol.retcode == ["Success"]
+    ref = orc.solve(vf, orc.Alg("EK1", q, "dynamic", False), tspan=vf.tspan, dt=2.0**-8, adaptive=True, abstol=1e-7, reltol=1e-5)
+    n = len(ref.t)
+    assert int(sol.nsaved[0]) == n and int(sol.destats.nreject[0]) == ref.nreject
+    np.testing.assert_allclose(sol.t[0][:n], ref.t, rtol=1e-6)
+    np.testing.assert_allclose(sol.u[0][:n], ref.u, rtol=1e-6, atol=1e-9)
+    # what no kernel covers is refused with a reason: odd d above state dimension 20
+    pkg.compile_rhs("UserL96d7", _l96_source("UserL96d7", 7), 7, 1)
+    with pytest.raises(pkg.OdefError, match="even d"):
+        pkg.Context("UserL96d7", 3, 1, 2)
+
+
 def test_user_vector_field_on_the_row_team_kernels_at_config2_size(pkg):
     """A user vector field with d = 5 at order 2 (D = 15: no compiled-in kernel has this shape) and 4 096 trajectories -- the
     ensemble size of BASELINE config 2, where the lane kernels would occupy 64 of the chip's 1 024 SIMDs: the library must

@@ -76,8 +76,14 @@ def test_user_vector_field_compiles_without_a_gpu(pkg):
         pkg.compile_rhs("Broken", "struct Broken { static constexpr int d = 2, np = 0; };", 2, 0)
     with pytest.raises(pkg.OdefError, match="d of the struct differs"):
         pkg.compile_rhs("WrongDim", USER_LORENZ.replace("UserLorenz", "WrongDim"), 2, 3)
-    with pytest.raises(pkg.OdefError, match="d must be in 1..10"):
-        pkg.compile_rhs("TooBig", USER_LORENZ.replace("UserLorenz", "TooBig"), 12, 3)
+    with pytest.raises(pkg.OdefError, match="d must be in 1..32"):
+        pkg.compile_rhs("TooBig", USER_LORENZ.replace("UserLorenz", "TooBig"), 40, 3)
+    # above d = 10 no lane kernel exists to try the text on: a probe kernel (f in double, in forward mode, on Taylor jets) does
+    l96 = "struct L96d12 { static constexpr int d = 12, np = 1; template <class T> __device__ static void f(const T (&u)[12], const double* p, T (&du)[12]) {" \
+          " for (int i = 0; i < 12; ++i) du[i] = (u[(i + 1) % 12] - u[(i + 10) % 12]) * u[(i + 11) % 12] - u[i] + p[0]; } };"
+    assert h.RHS[pkg.compile_rhs("L96d12", l96, 12, 1)] >= 100
+    with pytest.raises(pkg.OdefError, match="d of the struct differs"):
+        pkg.compile_rhs("L96d12b", l96.replace("L96d12", "L96d12b"), 14, 1)
     # a device function the compiler keeps out of line would be shared by kernels with different register budgets (a fault
     # on the GPU, nothing at compile time): the code object is inspected and refused
     helper = "__device__ __attribute__((noinline)) double odef_test_outlined(double x) { return 1.5 * x; }\n"
