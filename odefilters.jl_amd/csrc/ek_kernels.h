@@ -297,10 +297,10 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
         rest -= DPB - j;
         ++j;
       }
-      if (t < NTU) x[u] = mf::load_tile(BM, DP, j * mf::kB, (j + rest) * mf::kB);
+      if (t < NTU) x[u] = oc::load_tile_major(BM + W::tile_at(j, j + rest));
     }
 #pragma unroll
-    for (int j = 0; j < DPB; ++j) acc[j] = mf::load_tile(YT, DP, j * mf::kB, c0);
+    for (int j = 0; j < DPB; ++j) acc[j] = oc::load_tile_major(YT + W::tile_at(j, wave));
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int t = wave + u * DPB;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
     pij[k] = my[W::PIJV + k];
     pj[k] = my[W::PJV + k];
   }
-  oc::load_m<DPB>(my + W::MM, DP, lds);
+  oc::load_m<DPB>(my + W::MM, lds);
   __syncthreads();
   ODEF_SSTAMP(5);  // M, vectors -> LDS
   {

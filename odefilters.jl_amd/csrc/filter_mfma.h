@@ -702,7 +702,7 @@ struct MfmaFilter {
         double* c21 = sm + W::CW21;
         for (int e = G.lane; e < 256; e += 64) {
           const int r = e >> 4, c = e & 15;
-          c11[e] = WM[r * W::LDd + c];
+          c11[e] = (d >= 16 || (r < d && c < d)) ? WM[r * W::LDd + c] : 0.0;  // (d < 16: nothing of W lies beyond row / column d)
           c21[e] = (16 + r < d) ? WM[(16 + r) * W::LDd + c] : 0.0;
           c22[e] = (16 + r < d && 16 + c < d) ? WM[(16 + r) * W::LDd + 16 + c] : 0.0;
         }
@@ -1124,6 +1124,10 @@ struct MfmaFilter {
   template <bool HELPER>
   ODEF_MF_FN void run(const FilterParams& P, long i, int tid, double* __restrict__ sm) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef ODEF_MF_DEBUG_FILL  // (diagnostic: LDS pre-filled, NaN in [ODEF_MF_DEBUG_LO, ODEF_MF_DEBUG_HI) -- finds reads of LDS nobody wrote)
+    for (int e = tid; e < W::size; e += kMfBlock) sm[e] = (e >= (ODEF_MF_DEBUG_LO) && e < (ODEF_MF_DEBUG_HI)) ? __builtin_nan("") : 0.0;
+    __syncthreads();
+#endif
     if constexpr (HELPER) __builtin_amdgcn_s_setprio(3);  // the helper's serial work is what the others wait for: first pick at issue and instruction fetch
     double* m = sm + W::MV;
     double* sc = sm + W::SC;

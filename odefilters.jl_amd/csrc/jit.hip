@@ -371,9 +371,28 @@ bool compile(const std::string& src, const std::string& include_dir, std::vector
     // share an out-of-line callee, see out_of_line_device_functions)
     const char* argv_so[] = {cc, "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared", "-fno-crash-diagnostics", "-mllvm", "-amdgpu-function-calls=false",
                              inc.c_str(), srcp.c_str(), "-o", outp.c_str(), self.c_str(), nullptr};
-    const char* const* argv = shared_out ? argv_so : argv_co;
+    // $ODEFILTER_HIP_JIT_FLAGS: extra compiler flags, space-separated (diagnostic builds: e.g. the LDS poisoning of filter_mfma.h)
+    std::vector<std::string> extra;
+    if (const char* ef = getenv("ODEFILTER_HIP_JIT_FLAGS")) {
+      std::string tok;
+      for (const char* c = ef;; ++c) {
+        if (*c == ' ' || *c == 0) {
+          if (!tok.empty()) extra.push_back(tok);
+          tok.clear();
+          if (*c == 0) break;
+        } else
+          tok += *c;
+      }
+    }
+    std::vector<const char*> argv;
+    for (const char* const* a = shared_out ? argv_so : argv_co; *a; ++a) {
+      argv.push_back(*a);
+      if (a == (shared_out ? argv_so : argv_co))  // right behind the compiler's name
+        for (const auto& x : extra) argv.push_back(x.c_str());
+    }
+    argv.push_back(nullptr);
     pid_t pid = 0;
-    const int rc = posix_spawnp(&pid, cc, &fa, nullptr, const_cast<char* const*>(argv), environ);
+    const int rc = posix_spawnp(&pid, cc, &fa, nullptr, const_cast<char* const*>(argv.data()), environ);
     posix_spawn_file_actions_destroy(&fa);
     if (rc != 0) continue;
     spawned = true;

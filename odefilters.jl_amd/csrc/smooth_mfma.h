@@ -49,6 +49,11 @@ struct MfmaSmoothWs {
   // index the hand-over belongs to (-1: that record needs no algebra)
   static constexpr int MFV = MSV + DP, DLV = MFV + DP, PIJV = DLV + DP, FLG = PIJV + DP, PJV = FLG + 8;  // (PJV: P)
   static constexpr size_t size = (size_t)PJV + DP;
+  // ... where B, Y' and M lie TILE-MAJOR in their regions (BM, YT, MM): 16 x 16 tiles of 256 contiguous doubles, the tiles of a
+  // tile column one after the other -- what one wavefront of rts_smooth_sweeps_kernel loads is contiguous (a tile 2 KB, a tile
+  // column of Y' 2 KB x DPB) instead of 128-byte pieces DP doubles apart
+  __host__ __device__ static constexpr int tile_at(int tr, int tc) { return (tc * DPB + tr) * 256; }
+  __host__ __device__ static constexpr int tm(int r, int c) { return tile_at(r >> 4, c >> 4) + (r & 15) * 16 + (c & 15); }
   // LDS (doubles): factorisation scratch, then the vectors
   static constexpr int kChol = mf::CholLds<DPB>::size;
   static constexpr int MF = kChol, MS = MF + DP, MP = MS + DP, DL = MP + DP, PJ = DL + DP, PIJ = PJ + DP;

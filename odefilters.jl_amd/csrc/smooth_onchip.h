@@ -38,10 +38,21 @@ struct Products {
   __host__ __device__ static constexpr int sw(int r, int c) { return r * 16 + (c ^ ((r >> 1) << 1)); }
 };
 
-// M (full symmetric DP x DP, row-major, leading dimension ld) -> LDS, upper tiles in row order; the workgroup has DPB
-// wavefronts, wavefront w takes the tiles w, w + DPB, ...: all its loads in flight, then the stores
+// one 16 x 16 tile of a tile-major matrix (256 contiguous doubles at `tile`) in the accumulator layout: register v = rows
+// 4 v + l / 16, column l % 16 -- 512 contiguous bytes per load instruction
+__device__ __attribute__((always_inline)) inline d4 load_tile_major(const double* __restrict__ tile) {
+  const int l = (int)threadIdx.x & 63;
+  d4 t;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) t[v] = tile[64 * v + l];
+  return t;
+}
+
+// M (symmetric, tile-major with the tiles of a tile column one after the other: tile (tr, tc) at (tc DPB + tr) 256; upper tiles
+// present) -> LDS, upper tiles in row order; the workgroup has DPB wavefronts, wavefront w takes the tiles w, w + DPB, ...: all
+// its loads in flight, then the stores
 template <int DPB>
-__device__ __attribute__((always_inline)) inline void load_m(const double* __restrict__ MM, int ld, double* __restrict__ lds) {
+__device__ __attribute__((always_inline)) inline void load_m(const double* __restrict__ MM, double* __restrict__ lds) {
   using Pr = Products<DPB>;
   constexpr int PER = (Pr::NTU + DPB - 1) / DPB;
   const int tid = (int)threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
@@ -54,7 +65,7 @@ __device__ __attribute__((always_inline)) inline void load_m(const double* __res
       rest -= DPB - j;
       ++j;
     }
-    if (t < Pr::NTU) x[u] = mf::load_tile(MM, ld, j * 16, (j + rest) * 16);
+    if (t < Pr::NTU) x[u] = load_tile_major(MM + ((j + rest) * DPB + j) * 256);
   }
 #pragma unroll
   for (int u = 0; u < PER; ++u) {

@@ -11,7 +11,7 @@
 // dense output and sampling run) wrote X, re-read it for Y', re-read Y' for B -- 1.35 MB written and 1.15 MB fetched per
 // trajectory and record (rocprofv3 PMC), HBM-bound at 0.75 ms per record of 2 048 trajectories.
 //
-// B and M leave as upper tiles only (what rts_smooth_sweeps_kernel loads), X not at all: the on-chip kernel reads the
+// B, Y' and M leave tile-major (MfmaSmoothWs::tm), B and M as upper tiles only (what rts_smooth_sweeps_kernel loads), X not at all: the on-chip kernel reads the
 // record itself for Sigma^s = X + G M G'.  Same arithmetic, term by term, as mfma_predict_phase.
 #pragma once
 #include "smooth_mfma.h"
@@ -112,7 +112,7 @@ __device__ __attribute__((always_inline)) inline void smooth_predict_record(cons
   double* YT = ws + W::YT;
   double* BM = ws + W::BM;
   double* MM = ws + W::MM;
-  for (int k = D + tid; k < DP; k += nth) BM[k * DP + k] = 1.0;
+  for (int k = D + tid; k < DP; k += nth) BM[W::tm(k, k)] = 1.0;
   for (int it = tid; it < d * d; it += nth) {
     const int a = it / d, b = it % d;
     double x[NB][NB];
@@ -136,7 +136,7 @@ __device__ __attribute__((always_inline)) inline void smooth_predict_record(cons
 #pragma unroll
         for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * x[j][k];
         y[k] = t;
-        YT[r * DP + k * d + b] = t;
+        YT[W::tm(r, k * d + b)] = t;
       }
 #pragma unroll
       for (int K = 0; K < NB; ++K) {
@@ -146,8 +146,8 @@ __device__ __attribute__((always_inline)) inline void smooth_predict_record(cons
         if (a == b) bv += sigma2 * pc.Qt[J][K];
         const int c = K * d + b;
         if ((c >> 4) >= (r >> 4)) {  // (the tiles on and above the diagonal: all that is read)
-          BM[r * DP + c] = bv;
-          MM[r * DP + c] = sg[K] * (pjb[J] * pjb[K]) - bv;
+          BM[W::tm(r, c)] = bv;
+          MM[W::tm(r, c)] = sg[K] * (pjb[J] * pjb[K]) - bv;
         }
       }
     }

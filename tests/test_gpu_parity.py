@@ -1246,6 +1246,42 @@ def test_user_vector_field_on_the_matrix_core_kernels(pkg):
         pkg.Context("UserL96d7", 3, 1, 2)
 
 
+@pytest.mark.parametrize("d,q", [(12, 2), (8, 3), (4, 5)])
+def test_matrix_core_filter_reads_no_lds_it_did_not_write(pkg, d, q, monkeypatch):
+    """Shapes with fewer than 16 rows per derivative block run the workgroup-per-trajectory filter with partly filled 16 x 16
+    blocks.  A diagnostic build ($ODEFILTER_HIP_JIT_FLAGS -> ODEF_MF_DEBUG_FILL, csrc/filter_mfma.h) starts every workgroup
+    with its LDS full of NaNs: whatever the kernel reads without having written it poisons the result.  (Found this way: the
+    factorisation of H Q H' copied a 16 x 16 block out of a d x d matrix without looking at d -- results depended on what the
+    previous kernel had left in LDS.)"""
+    monkeypatch.setenv("ODEFILTER_HIP_JIT_FLAGS", "-DODEF_MF_DEBUG_FILL=1 -DODEF_MF_DEBUG_LO=0 -DODEF_MF_DEBUG_HI=W::size")
+    name = f"PoisonL96d{d}q{q}"
+    pkg.compile_rhs(name, _l96_source(name, d), d, 1)
+
+    def f(u, p, t):
+        return [(u[(i + 1) % d] - u[(i + d - 2) % d]) * u[(i + d - 1) % d] - u[i] + p[0] for i in range(d)]
+
+    def jac(u, p, t):
+        J = np.zeros((d, d))
+        for i in range(d):
+            ip, im2, im1 = (i + 1) % d, (i + d - 2) % d, (i + d - 1) % d
+            J[i, ip] += u[im1]
+            J[i, im2] -= u[im1]
+            J[i, im1] += u[ip] - u[im2]
+            J[i, i] -= 1.0
+        return J
+
+    u0 = 1.0 + np.random.default_rng(d).normal(size=d)
+    vf = orc.VectorField(name, 100, d, 1, f, jac, u0, np.array([8.0]), (0.0, 0.1))
+    ns, dt = 12, 2.0**-7
+    sol = pkg.solve(pkg.ODEProblem(name, vf.u0, (0.0, ns * dt), vf.p), pkg.EK1(order=q), dt=dt, adaptive=False)
+    assert sol.retcode == ["Success"] and "ek_filter_mfma_kernel" in sol.ctx.kernel_name(0)
+    ref = orc.solve(vf, orc.EK1(order=q), tspan=(0.0, ns * dt), dt=dt)
+    np.testing.assert_allclose(sol.u[0], ref.u, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(sol.x_filt_mean()[0][:, :d], ref.means(smoothed=False)[:, :d], rtol=1e-10, atol=1e-13)
+    assert np.isfinite(sol.x_smooth_cov()[0]).all() and np.isfinite(sol.x_filt_cov()[0]).all()
+    assert P.cov_err(sol.x_smooth_cov()[0], ref.covs(smoothed=True)) < 1e-5
+
+
 def test_user_vector_field_on_the_row_team_kernels_at_config2_size(pkg):
     """A user vector field with d = 5 at order 2 (D = 15: no compiled-in kernel has this shape) and 4 096 trajectories -- the
     ensemble size of BASELINE config 2, where the lane kernels would occupy 64 of the chip's 1 024 SIMDs: the library must

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64 * DPB) void k_products(const double* __restrict_
 #pragma unroll
     for (int j = 0; j < DPB; ++j) acc[j] = mf::load_tile(g, DP, j * 16, wave * 16);
     __syncthreads();
-    oc::load_m<DPB>(m, DP, lds);
+    oc::load_m<DPB>(m, lds);
     __syncthreads();
     d4 r[Pr::WMAX];
     oc::gmgt<DPB>(acc, lds, r);
@@ -64,9 +64,12 @@ int main(int argc, char** argv) {
     }
   double *dG, *dM, *dR;
   hipMalloc(&dG, (size_t)nwg * DP * DP * 8); hipMalloc(&dM, (size_t)nwg * DP * DP * 8); hipMalloc(&dR, (size_t)nwg * DP * DP * 8);
+  std::vector<double> Mt((size_t)DP * DP);  // tile-major, as the predict kernel leaves M (MfmaSmoothWs::tm)
+  for (int a = 0; a < DP; ++a)
+    for (int b = 0; b < DP; ++b) Mt[(size_t)((b / 16) * DPB + a / 16) * 256 + (a % 16) * 16 + b % 16] = M[a * DP + b];
   for (int w = 0; w < nwg; ++w) {
     hipMemcpy(dG + (size_t)w * DP * DP, G.data(), G.size() * 8, hipMemcpyHostToDevice);
-    hipMemcpy(dM + (size_t)w * DP * DP, M.data(), M.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dM + (size_t)w * DP * DP, Mt.data(), Mt.size() * 8, hipMemcpyHostToDevice);
   }
   hipMemset(dR, 0, (size_t)nwg * DP * DP * 8);
   const size_t ldsb = (size_t)Pr::size * 8;
