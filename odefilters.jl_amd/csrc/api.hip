@@ -345,7 +345,7 @@ int odef_create(odef_ctx** out, const odef_config* cfg) {
   hipError_t e = hipSetDevice(c->device);
   if (e == hipSuccess && jit_team) {
     std::string jerr;
-    c->team = jit_get_team(cfg->rhs_id, c->q, cfg->alg == ODEF_EK1, jerr);
+    c->team = jit_get_team(cfg->rhs_id, c->q, cfg->alg == ODEF_EK1, team_abi_stamp(), jerr);
     c->team_path = c->team != nullptr;
     if (!c->team) {
       g_create_error = "odef_create: " + jerr;  // the whole compiler log

@@ -31,7 +31,7 @@ JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& e
 // The workgroup-per-trajectory path for a run-time compiled field (state dimension above 20, even d <= 32): compiles
 // (once per (rhs, order, alg); minutes) a host + device shared object around the field and returns its launch table (launch.h)
 struct TeamLaunch;
-const TeamLaunch* jit_get_team(int rhs_id, int q, int ek1, std::string& err);
+const TeamLaunch* jit_get_team(int rhs_id, int q, int ek1, unsigned long abi_stamp, std::string& err);  // abi_stamp: team_abi_stamp() of the library
 // `block` threads per workgroup (64: the lane and LDS row-team kernels; 256: rows_kernels.h); params: pointer to the kernel's
 // single by-value parameter struct
 int jit_launch(hipFunction_t f, unsigned gx, unsigned gy, const void* params, hipStream_t s, unsigned block = 64);

@@ -191,6 +191,7 @@ std::string team_translation_unit(const JitRhs& r, int q, int ek1) {
   s += "static int jit_sample(int q, const SampleParams& P, double* ws, hipStream_t s) { return team_sample<" + DD + ", " + Q + ">(q, P, ws, s); }\n";
   s += "static size_t jit_smooth_ws(int q) { return team_smooth_ws<" + DD + ", " + Q + ">(q); }\n";
   s += "}  // namespace odef\n";
+  s += "extern \"C\" unsigned long odef_jit_abi() { return odef::team_abi_stamp(); }\n";
   s += "extern \"C\" const odef::TeamLaunch* odef_jit_team() {\n"
        "  using namespace odef;\n"
        "  static const TeamLaunch t = {" + DD + ", jit_filter, jit_smooth, jit_smooth_staged, jit_dense, jit_sample, jit_smooth_ws};\n"
@@ -544,7 +545,7 @@ JitModule* jit_get_module(int rhs_id, int q, int ek1, int device, std::string& e
   return out;
 }
 
-const TeamLaunch* jit_get_team(int rhs_id, int q, int ek1, std::string& err) {
+const TeamLaunch* jit_get_team(int rhs_id, int q, int ek1, unsigned long abi_stamp, std::string& err) {
   // as jit_get_module: the compiler (minutes for these kernels) runs outside the registry lock
   const auto key = std::make_tuple(rhs_id, q, ek1);
   JitRhs r;
@@ -566,6 +567,12 @@ const TeamLaunch* jit_get_team(int rhs_id, int q, int ek1, std::string& err) {
   Entry entry = (Entry)dlsym(handle, "odef_jit_team");
   if (!entry) {
     err = "odef_jit_team missing from the run-time compiled module";
+    return nullptr;
+  }
+  using Stamp = unsigned long (*)();
+  Stamp stamp = (Stamp)dlsym(handle, "odef_jit_abi");
+  if (!stamp || stamp() != abi_stamp) {
+    err = "the run-time compiled module was built from headers that do not match this library (parameter struct layouts differ): rebuild libodefilter_hip.so or point ODEFILTER_HIP_INCLUDE at its csrc";
     return nullptr;
   }
   const TeamLaunch* t = entry();

@@ -42,6 +42,11 @@ struct TeamLaunch {
   int (*sample)(int q, const SampleParams& P, double* ws, hipStream_t s);
   size_t (*smooth_ws)(int q);  // doubles of workspace per trajectory (smoother) / per grid slot (dense output, sampling)
 };
+// Layout stamp of what crosses between the library and a run-time compiled module of this path (jit.hip builds one from the
+// headers it finds at run time: a tree whose headers moved on without a rebuild of the library must be refused, not launched)
+inline unsigned long team_abi_stamp() {
+  return sizeof(FilterParams) * 1000003ul + sizeof(SmoothParams) * 10007ul + sizeof(DenseParams) * 101ul + sizeof(SampleParams) + sizeof(TeamLaunch) * 7ul;
+}
 const TeamLaunch* team_pleiades();  // d = 28 (BASELINE config 4)
 const TeamLaunch* team_lorenz96();  // d = 16: the same kernels on a second shape
 const TeamLaunch* team_launch(int rhs_id);  // nullptr: the field runs on the lane / row-team kernels
