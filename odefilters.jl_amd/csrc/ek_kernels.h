@@ -418,7 +418,7 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
   // What follows the sweeps, still on chip (smooth_onchip.h): G' never leaves the accumulators.
   //   m^s = P^-1 (P m + G delta)          (src/smoothing.jl:44, :26) -- the record and the carried mean of the pass
   //   Sigma^s = P^-1 (X + G M G') P^-1    M into the LDS the factor has left; the result tiles go straight to the record in
-  //                                       the stage (packed lower triangle) and to the carried full matrix SG
+  //                                       the stage (packed lower triangle) and to the carried matrix SG (upper tiles, tile-major)
   using Pr = oc::Products<DPB>;
   constexpr int D = W::D;
   const size_t N = (size_t)P.N;
@@ -432,7 +432,48 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
     pij[k] = my[W::PIJV + k];
     pj[k] = my[W::PJV + k];
   }
-  oc::load_m<DPB>(my + W::MM, lds);
+  __syncthreads();  // (the vectors are there)
+  // M = P Sigma^s_+ P - B into the LDS the factor has left (swizzled upper tiles, smooth_onchip.h): Sigma^s_+ as this kernel
+  // wrote it one record earlier (or the set-up did), B read a second time -- half of a wavefront's tiles at a time, G' keeps
+  // the other registers
+  {
+    constexpr int NTU = Pr::NTU, PER = (NTU + DPB - 1) / DPB, HALF = (PER + 1) / 2;
+    const double* SGr = my + W::SG;
+#pragma unroll
+    for (int h0 = 0; h0 < PER; h0 += HALF) {
+      mf::d4 sg[HALF], bt[HALF];
+#pragma unroll
+      for (int u = h0; u < h0 + HALF && u < PER; ++u) {
+        const int t = wave + u * DPB;
+        int j = 0, rest = t;
+        while (rest >= DPB - j) {
+          rest -= DPB - j;
+          ++j;
+        }
+        if (t < NTU) {
+          sg[u - h0] = oc::load_tile_major(SGr + W::tile_at(j, j + rest));
+          bt[u - h0] = oc::load_tile_major(BM + W::tile_at(j, j + rest));
+        }
+      }
+#pragma unroll
+      for (int u = h0; u < h0 + HALF && u < PER; ++u) {
+        const int t = wave + u * DPB;
+        int j = 0, rest = t;
+        while (rest >= DPB - j) {
+          rest -= DPB - j;
+          ++j;
+        }
+        if (t < NTU) {
+          double* dstm = lds + Pr::kM + t * 256;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int rr = 4 * v + (l >> 4), cc = l & 15;
+            dstm[Pr::sw(rr, cc)] = sg[u - h0][v] * (pj[j * mf::kB + rr] * pj[(j + rest) * mf::kB + cc]) - bt[u - h0][v];
+          }
+        }
+      }
+    }
+  }
   __syncthreads();
   ODEF_SSTAMP(5);  // M, vectors -> LDS
   {
@@ -447,7 +488,7 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
   }
   ODEF_SSTAMP(6);  // mean
   mf::d4 r[Pr::WMAX];
-  oc::gmgt<DPB>(acc, lds, r);
+  oc::gmgt<DPB, (W::D - 16 * (DPB - 1) + 3) / 4>(acc, lds, r);
   ODEF_SSTAMP(7);  // G M G'
   // X = P Sigma_s P comes from the record itself (packed lower triangle, still the filter's): the tile below the diagonal of
   // each pair, whole rows of it contiguous
@@ -481,7 +522,7 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
 #pragma unroll
   for (int w = 0; w < Pr::WMAX; ++w) {
     if (w < Pr::owned(wave)) {
-      // tile (cw, wave) of the sum and, through LDS, its transpose (wave, cw): both leave as whole 128-byte rows.  The record
+      // tile (cw, wave) of the sum and, through LDS, its transpose (wave, cw): whole rows leave.  The record
       // takes whichever of the two lies below the diagonal -- the transpose if the window wrapped (then X was read as that
       // transpose too).
       const int cw = wave + w < DPB ? wave + w : wave + w - DPB;
@@ -500,7 +541,7 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
           if (b > a) o[v] = ot[v];
           if (b <= a && a < D) dst[a * (a + 1) / 2 + b] = o[v];
         }
-        mf::store_tile(SG, DP, c0, c0, o);
+        oc::store_tile_major(SG + W::tile_at(wave, wave), o);
       } else {
         const bool lower = cw > wave;
 #pragma unroll
@@ -508,8 +549,7 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
           const int a = (lower ? cw * mf::kB : c0) + 4 * v + (l >> 4), b = (lower ? c0 : cw * mf::kB) + (l & 15);
           if (a < D) dst[a * (a + 1) / 2 + b] = lower ? o[v] : ot[v];
         }
-        mf::store_tile(SG, DP, cw * mf::kB, c0, o);
-        mf::store_tile(SG, DP, c0, cw * mf::kB, ot);
+        oc::store_tile_major(SG + (lower ? W::tile_at(wave, cw) : W::tile_at(cw, wave)), lower ? ot : o);  // (the tile above the diagonal)
       }
     }
   }

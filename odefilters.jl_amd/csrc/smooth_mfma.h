@@ -49,7 +49,8 @@ struct MfmaSmoothWs {
   // index the hand-over belongs to (-1: that record needs no algebra)
   static constexpr int MFV = MSV + DP, DLV = MFV + DP, PIJV = DLV + DP, FLG = PIJV + DP, PJV = FLG + 8;  // (PJV: P)
   static constexpr size_t size = (size_t)PJV + DP;
-  // ... where B, Y' and M lie TILE-MAJOR in their regions (BM, YT, MM): 16 x 16 tiles of 256 contiguous doubles, the tiles of a
+  // ... where B, Y' and the carried Sigma^s lie TILE-MAJOR in their regions (BM, YT, SG; B and Sigma^s: the tiles on and above
+  // the diagonal): 16 x 16 tiles of 256 contiguous doubles, the tiles of a
   // tile column one after the other -- what one wavefront of rts_smooth_sweeps_kernel loads is contiguous (a tile 2 KB, a tile
   // column of Y' 2 KB x DPB) instead of 128-byte pieces DP doubles apart
   __host__ __device__ static constexpr int tile_at(int tr, int tc) { return (tc * DPB + tr) * 256; }
@@ -301,8 +302,13 @@ __device__ __attribute__((always_inline)) inline void smooth_mfma_traj(const Smo
         TriWalk tw(tid);
         for (int e = tid; e < TRI; e += nth, tw.advance(nth)) {
           const double v = src[e];
-          SG[tw.a * DP + tw.b] = v;
-          SG[tw.b * DP + tw.a] = v;
+          if constexpr (SPLITK) {  // the split pass carries Sigma^s as upper tiles, tile-major (W::tm), diagonal tiles complete
+            SG[W::tm(tw.b, tw.a)] = v;
+            if ((tw.a >> 4) == (tw.b >> 4)) SG[W::tm(tw.a, tw.b)] = v;
+          } else {
+            SG[tw.a * DP + tw.b] = v;
+            SG[tw.b * DP + tw.a] = v;
+          }
         }
         continue;
       }

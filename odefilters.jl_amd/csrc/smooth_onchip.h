@@ -48,6 +48,12 @@ __device__ __attribute__((always_inline)) inline d4 load_tile_major(const double
   return t;
 }
 
+__device__ __attribute__((always_inline)) inline void store_tile_major(double* __restrict__ tile, const d4& t) {
+  const int l = (int)threadIdx.x & 63;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) tile[64 * v + l] = t[v];
+}
+
 // M (symmetric, tile-major with the tiles of a tile column one after the other: tile (tr, tc) at (tc DPB + tr) 256; upper tiles
 // present) -> LDS, upper tiles in row order; the workgroup has DPB wavefronts, wavefront w takes the tiles w, w + DPB, ...: all
 // its loads in flight, then the stores
@@ -80,7 +86,9 @@ __device__ __attribute__((always_inline)) inline void load_m(const double* __res
 
 // acc[k] = G'[k, c] (c = this wavefront's tile column), M in LDS (load_m, synchronised by the caller).  On return r[w] = R[c + w mod DPB, c]
 // for w < owned(c).  Contains workgroup barriers: every wavefront of the workgroup must call it.
-template <int DPB>
+// KL: k-steps (of 4 rows) of the LAST tile row that hold state components -- the rows of G' behind the state dimension are
+// zero, and the products skip them (D = 168: 2 of 4)
+template <int DPB, int KL = 4>
 __device__ __attribute__((always_inline)) inline void gmgt(const d4 (&acc)[DPB], double* __restrict__ lds, d4 (&r)[Products<DPB>::WMAX]) {
   using Pr = Products<DPB>;
   const int tid = (int)threadIdx.x, c = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
@@ -107,7 +115,7 @@ __device__ __attribute__((always_inline)) inline void gmgt(const d4 (&acc)[DPB],
       constexpr int t = i <= k ? Pr::tix(i, k) : Pr::tix(k, i);
       const double* m = lds + Pr::kM + t * 256;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) z = mf::mfma(m[i <= k ? off_d[kk] : off_t[kk]], acc[k][kk], z);
+      for (int kk = 0; kk < (k == DPB - 1 ? KL : 4); ++kk) z = mf::mfma(m[i <= k ? off_d[kk] : off_t[kk]], acc[k][kk], z);
       asm volatile("" ::: "memory");  // (keeps the compiler from hoisting, and spilling, the fragment reads of all later tiles)
     });
     int oz = off_z;  // (a fresh copy per row: the addresses of the owned tiles live for one row, not for the whole product)
@@ -123,7 +131,7 @@ __device__ __attribute__((always_inline)) inline void gmgt(const d4 (&acc)[DPB],
         const int cw = c + w < DPB ? c + w : c + w - DPB;
         const double* zt = zrow + cw * 256;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) r[w] = mf::mfma(zt[64 * kk], acc[i][kk], r[w]);
+        for (int kk = 0; kk < (i == DPB - 1 ? KL : 4); ++kk) r[w] = mf::mfma(zt[64 * kk], acc[i][kk], r[w]);
         asm volatile("" ::: "memory");
       }
     }

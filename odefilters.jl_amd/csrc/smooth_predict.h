@@ -1,17 +1,18 @@
 // First kernel of a record of the D = 168 smoother's split pass (src/smoothing.jl:11-35): unpack and predict.
 //
 //   X = P Sigma_s P              the filter record of the stage (packed lower triangle), staged ONCE into LDS
-//   Y' = A X,  B = A X A' + sigma^2 Q,  M = P Sigma^s_{s+1} P - B,  m^- = A P m,  delta = P m^s_{s+1} - m^-
+//   Y' = A X,  B = A X A' + sigma^2 Q,  m^- = A P m,  delta = P m^s_{s+1} - m^-
+//   (M = P Sigma^s_{s+1} P - B is formed by the on-chip kernel, from the Sigma^s tiles it wrote itself one record earlier)
 //
 // The prior is A = At (x) I_d (src/priors.jl): for every pair of components (a, b) the (q+1) x (q+1) block
-// X_ab[j][k] = X[(j, a), (k, b)] maps onto the same block of Y', B and M -- Y'_ab = At X_ab, B_ab = Y'_ab At' (+ sigma^2 Qt on
+// X_ab[j][k] = X[(j, a), (k, b)] maps onto the same block of Y' and B -- Y'_ab = At X_ab, B_ab = Y'_ab At' (+ sigma^2 Qt on
 // a = b).  One thread per pair: 36 values out of LDS, two small triangular products in registers, and each result goes to the
 // workspace once (runs of d contiguous doubles across the lanes of a wavefront).  Neither X nor Y' is read back: the
 // workspace kernel this replaces for the split pass (mfma_predict_phase, smooth_mfma.h, still what the persistent kernel,
 // dense output and sampling run) wrote X, re-read it for Y', re-read Y' for B -- 1.35 MB written and 1.15 MB fetched per
 // trajectory and record (rocprofv3 PMC), HBM-bound at 0.75 ms per record of 2 048 trajectories.
 //
-// B, Y' and M leave tile-major (MfmaSmoothWs::tm), B and M as upper tiles only (what rts_smooth_sweeps_kernel loads), X not at all: the on-chip kernel reads the
+// B and Y' leave tile-major (MfmaSmoothWs::tm), B as upper tiles only (what rts_smooth_sweeps_kernel loads), X not at all: the on-chip kernel reads the
 // record itself for Sigma^s = X + G M G'.  Same arithmetic, term by term, as mfma_predict_phase.
 #pragma once
 #include "smooth_mfma.h"
@@ -55,7 +56,7 @@ __device__ __attribute__((always_inline)) inline void smooth_predict_record(cons
   if (h == 0.0) {  // src/smoothing.jl:13-16: a repeated save time, the smoothed state carries over
     for (int k = tid; k < D; k += nth) P.smean[((size_t)s * D + k) * N + i] = ws[W::MSV + k];
     TriWalk tw(tid);
-    for (int e = tid; e < TRI; e += nth, tw.advance(nth)) rec[e] = SG[tw.a * DP + tw.b];
+    for (int e = tid; e < TRI; e += nth, tw.advance(nth)) rec[e] = SG[W::tm(tw.b, tw.a)];  // (carried as upper tiles)
     if (tid == 0) ws[W::FLG] = -1.0;
     return;
   }
@@ -108,10 +109,9 @@ __device__ __attribute__((always_inline)) inline void smooth_predict_record(cons
     ws[W::PIJV + k] = pij;
     ws[W::PJV + k] = pj;
   }
-  // the padding block of B is the identity (nothing else writes there; M and Y' are zero there from the set-up)
+  // the padding block of B is the identity (nothing else writes there; Sigma^s and Y' are zero there from the set-up)
   double* YT = ws + W::YT;
   double* BM = ws + W::BM;
-  double* MM = ws + W::MM;
   for (int k = D + tid; k < DP; k += nth) BM[W::tm(k, k)] = 1.0;
   for (int it = tid; it < d * d; it += nth) {
     const int a = it / d, b = it % d;
@@ -127,9 +127,7 @@ __device__ __attribute__((always_inline)) inline void smooth_predict_record(cons
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
       const int r = J * d + a;
-      double sg[NB], y[NB];
-#pragma unroll
-      for (int K = 0; K < NB; ++K) sg[K] = SG[r * DP + K * d + b];
+      double y[NB];
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         double t = x[J][k];
@@ -145,10 +143,7 @@ __device__ __attribute__((always_inline)) inline void smooth_predict_record(cons
         for (int k = K + 1; k < NB; ++k) bv += pc.At[K][k] * y[k];
         if (a == b) bv += sigma2 * pc.Qt[J][K];
         const int c = K * d + b;
-        if ((c >> 4) >= (r >> 4)) {  // (the tiles on and above the diagonal: all that is read)
-          BM[W::tm(r, c)] = bv;
-          MM[W::tm(r, c)] = sg[K] * (pjb[J] * pjb[K]) - bv;
-        }
+        if ((c >> 4) >= (r >> 4)) BM[W::tm(r, c)] = bv;  // (the tiles on and above the diagonal: all that is read)
       }
     }
   }
