@@ -271,6 +271,9 @@ template <int d, int q>
 __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth_sweeps_kernel(const SmoothParams P, double* ws) {
   using W = MfmaSmoothWs<d, q + 1>;
   constexpr int DPB = W::DPB, DP = W::DP, LDT = 17, TSZ = mf::kB * LDT;
+  // k-steps (of 4 rows) of the last tile row that hold state components: the rows of Y' / G' behind the state dimension are zero,
+  // the sweeps and the products skip them
+  constexpr int KL = (W::D - 16 * (DPB - 1) + 3) / 4;
   extern __shared__ double lds[];
   const long i = team_traj(P.N);
   if (i < 0) return;
@@ -386,7 +389,7 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
     const double* w = lds + tix(j, j) * TSZ;
     mf::d4 z0 = mf::zero4();
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) z0 = mf::mfma(w[(l & 15) * LDT + 4 * kk + (l >> 4)], acc[j][kk], z0);
+    for (int kk = 0; kk < (j == DPB - 1 ? KL : 4); ++kk) z0 = mf::mfma(w[(l & 15) * LDT + 4 * kk + (l >> 4)], acc[j][kk], z0);
     acc[j] = z0;
     const mf::d4 z = -z0;
     static_for<j + 1, DPB>([&](auto jpc) {
@@ -403,14 +406,14 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
     const double* w = lds + tix(j, j) * TSZ;
     mf::d4 g0 = mf::zero4();
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) g0 = mf::mfma(w[(4 * kk + (l >> 4)) * LDT + (l & 15)], acc[j][kk], g0);
+    for (int kk = 0; kk < (j == DPB - 1 ? KL : 4); ++kk) g0 = mf::mfma(w[(4 * kk + (l >> 4)) * LDT + (l & 15)], acc[j][kk], g0);
     acc[j] = g0;
     const mf::d4 g = -g0;
     static_for<0, j>([&](auto jpc) {
       constexpr int jp = decltype(jpc)::value;
       const double* t = lds + tix(jp, j) * TSZ;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) acc[jp] = mf::mfma(t[(l & 15) * LDT + 4 * ks + (l >> 4)], g[ks], acc[jp]);
+      for (int ks = 0; ks < (j == DPB - 1 ? KL : 4); ++ks) acc[jp] = mf::mfma(t[(l & 15) * LDT + 4 * ks + (l >> 4)], g[ks], acc[jp]);
       asm volatile("" ::: "memory");
     });
   });
@@ -488,7 +491,7 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
   }
   ODEF_SSTAMP(6);  // mean
   mf::d4 r[Pr::WMAX];
-  oc::gmgt<DPB, (W::D - 16 * (DPB - 1) + 3) / 4>(acc, lds, r);
+  oc::gmgt<DPB, KL>(acc, lds, r);
   ODEF_SSTAMP(7);  // G M G'
   // X = P Sigma_s P comes from the record itself (packed lower triangle, still the filter's): the tile below the diagonal of
   // each pair, whole rows of it contiguous
