@@ -918,8 +918,30 @@ struct MfmaFilter {
       // in place the elements of a record lie N doubles apart (8 useful bytes per line written); staged, the record is one
       // contiguous run that this workgroup completes line by line within the save
       const bool staged = P.cov_stage != nullptr;
-      double* rec = staged ? P.cov_stage + ((size_t)slot * N + (size_t)i) * (size_t)P.stage_ld : P.cov + (size_t)slot * TRI * N + i;
-      const size_t es = staged ? 1 : N;
+      if (staged) {
+        // element (a, b), a <= b, of tile (Q, Pc) sits at b (b + 1) / 2 + a of the record: with b = Pc TR + j, a = Q TR + 4 v + g that is
+        // [a wavefront-uniform part] + (Pc TR) j + [j (j + 1) / 2 + g + 4 v] -- one 32-bit multiply-add per tile and lane (written as
+        // 64-bit index arithmetic per element the save cost 3 ms of the every-step filter's 34 at 2 048 x 64: the step body
+        // fills the instruction cache as it is).  Tried and dropped: the record written from the exchange copy of the tiles
+        // at the start of the next step, by all nine wavefronts in one rolled, fully coalesced loop -- slower (39.0 against 37.2 ms).
+        double* rec = P.cov_stage + ((size_t)slot * N + (size_t)i) * (size_t)P.stage_ld;
+        const int lane_off = G.j * (G.j + 1) / 2 + G.g;
+        static_for<0, NS>([&](auto sc_) {
+          constexpr int s = decltype(sc_)::value;
+          if (s < S.n) {
+            const int Q = S.tq[s], Pc = S.tp[s], mcol = Pc * TR;
+            const int base = mcol * (mcol + 1) / 2 + Q * TR;
+            const int off = base + mcol * G.j + lane_off;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+              if (G.ok[v] && (Q < Pc || 4 * v + G.g <= G.j)) rec[off + 4 * v] = T[s][v];
+          }
+        });
+        if (tid == 0) P.diff[(size_t)slot * N + i] = diffusion;
+        return;
+      }
+      double* rec = P.cov + (size_t)slot * TRI * N + i;
+      const size_t es = N;
       static_for<0, NS>([&](auto sc_) {
         constexpr int s = decltype(sc_)::value;
         if (s < S.n) {
