@@ -64,6 +64,8 @@ end
 Hand a user vector field to the library as HIP C++ source (`odef_rhs_compile`, include/odefilter.h): the stand-in for
 the closure `prob.f` (+ `f.jac`) that `perform_step!` calls at src/perform_step.jl:106,116-121.  The returned id goes
 into `OdefConfig.rhs_id` (register it in `RHS_IDS` under a symbol to use it with `EnsembleHIP(:name)`).
+State dimensions d(q+1) <= 20 (d <= 10) run on the lane / row-team kernels; above that `odef_create` builds the
+matrix-core workgroup kernels around the field for the requested order and algorithm (even d <= 32, d(q+1) <= 176).
 """
 function compile_rhs(name::AbstractString, source::AbstractString, d::Integer, n_params::Integer;
                      include_dir::Union{Nothing,AbstractString}=nothing)

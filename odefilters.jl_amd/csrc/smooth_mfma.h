@@ -45,6 +45,7 @@ struct MfmaSmoothWs {
   static constexpr int D = d * NB, DPB = (D + 15) / 16, DP = DPB * 16, MAT = DP * DP;
   static constexpr int X = 0, YT = MAT, BM = 2 * MAT, LM = 3 * MAT, MM = 4 * MAT, Z2 = 5 * MAT, SG = 6 * MAT;
   static constexpr int MSV = 7 * MAT;  // the carried smoothed mean between the launches of a staged pass
+  // (the split pass -- smooth_predict.h, rts_smooth_sweeps_kernel -- uses YT, BM and SG of the matrices only, tile-major, see below)
   // split pass (one kernel per phase): what the phases of a record hand over -- P m, delta, P^-1 (vectors) and the record
   // index the hand-over belongs to (-1: that record needs no algebra)
   static constexpr int MFV = MSV + DP, DLV = MFV + DP, PIJV = DLV + DP, FLG = PIJV + DP, PJV = FLG + 8;  // (PJV: P)
