@@ -468,9 +468,16 @@ ODEF_TV_INLINE void fb1(double& acc, double src, double b) {
   if constexpr (NEG) fnma_bc<K>(acc, src, b);
   else fma_bc<K>(acc, src, b);
 }
+// runs of 5 and more as ONE asm statement (one s_nop per run instead of one per group of four; generated)
+#include "team_vec_groups.h"
 template <bool NEG, int C0, int n>
 ODEF_TV_INLINE void fb_cols(double* acc, double src, double b) {
-  if constexpr (n >= 4) {
+  if constexpr (n > 12) {
+    fb_cols_12<NEG, C0>(acc, src, b);
+    fb_cols<NEG, C0 + 12, n - 12>(acc, src, b);
+  } else if constexpr (n >= 5) {
+    fb_cols_wide<NEG, C0, n>(acc, src, b);
+  } else if constexpr (n >= 4) {
     ODEF_TV_FB_DISPATCH(ODEF_TV_FB4_COLS);
     fb_cols<NEG, C0 + 4, n - 4>(acc, src, b);
   } else if constexpr (n == 3) {
@@ -483,7 +490,12 @@ ODEF_TV_INLINE void fb_cols(double* acc, double src, double b) {
 }
 template <bool NEG, int K, int n>
 ODEF_TV_INLINE void fb_rows(double* acc, const double* src, double b) {
-  if constexpr (n >= 4) {
+  if constexpr (n > 14) {
+    fb_rows_14<NEG, K>(acc, src, b);
+    fb_rows<NEG, K, n - 14>(acc + 14, src + 14, b);
+  } else if constexpr (n >= 5) {
+    fb_rows_wide<NEG, K, n>(acc, src, b);
+  } else if constexpr (n >= 4) {
     ODEF_TV_FB_DISPATCH(ODEF_TV_FB4_ROWS);
     fb_rows<NEG, K, n - 4>(acc + 4, src + 4, b);
   } else if constexpr (n == 3) {
@@ -496,7 +508,12 @@ ODEF_TV_INLINE void fb_rows(double* acc, const double* src, double b) {
 }
 template <bool NEG, int K, int n>
 ODEF_TV_INLINE void fb_dot(double& acc, const double* src, const double* b) {
-  if constexpr (n >= 4) {
+  if constexpr (n > 14) {
+    fb_dot_14<NEG, K>(acc, src, b);
+    fb_dot<NEG, K, n - 14>(acc, src + 14, b + 14);
+  } else if constexpr (n >= 5) {
+    fb_dot_wide<NEG, K, n>(acc, src, b);
+  } else if constexpr (n >= 4) {
     ODEF_TV_FB_DISPATCH(ODEF_TV_FB4_DOT);
     fb_dot<NEG, K, n - 4>(acc, src + 4, b + 4);
   } else if constexpr (n == 3) {
@@ -509,7 +526,12 @@ ODEF_TV_INLINE void fb_dot(double& acc, const double* src, const double* b) {
 }
 template <bool NEG, int C0, int n>
 ODEF_TV_INLINE void fb_lanes(double& acc, double src, const double* b) {
-  if constexpr (n >= 4) {
+  if constexpr (n > 14) {
+    fb_lanes_14<NEG, C0>(acc, src, b);
+    fb_lanes<NEG, C0 + 14, n - 14>(acc, src, b);
+  } else if constexpr (n >= 5) {
+    fb_lanes_wide<NEG, C0, n>(acc, src, b);
+  } else if constexpr (n >= 4) {
     ODEF_TV_FB_DISPATCH(ODEF_TV_FB4_LANES);
     fb_lanes<NEG, C0 + 4, n - 4>(acc, src, b);
   } else if constexpr (n == 3) {
