@@ -729,11 +729,9 @@ struct MfmaFilter {
     if constexpr (HELPER) {
       if (!fixed_diffusion) {
         double* w1 = sm + W::CWW1;
-        double* w2 = sm + W::CWW2;
         ODEF_MF_HSTAMP(0)
-        chol2_b(sm + W::CW22, w2, 16);
-        ODEF_MF_HSTAMP(2)
-        // y = L^-1 z: y1 = W11 z1, y2 = W22 (z2 - L21 y1); lanes 0..15 hold y1, lanes 16..31 hold y2
+        // y = L^-1 z: y1 = W11 z1 (the inverse of the first block exists: L21 = S21 W11' needed it), y2 from L22 y2 = z2 - L21 y1
+        // by substitution inside the factorisation of the second block (its inverse is needed by nobody)
         const int l = G.lane, r = l & 15;
         double y1 = 0.0;
 #pragma unroll
@@ -741,9 +739,8 @@ struct MfmaFilter {
         double t2 = z[16 + r];  // zero beyond d
 #pragma unroll
         for (int b = 0; b < 16; ++b) t2 -= sm[W::CWL + r * 16 + b] * __shfl(y1, b, 64);
-        double y2 = 0.0;
-#pragma unroll
-        for (int b = 0; b < 16; ++b) y2 += w2[r * 16 + b] * __shfl(t2, b, 64);
+        ODEF_MF_HSTAMP(2)
+        const double y2 = mf::diag_block_factor_solve(sm + W::CW22, t2);
         const double acc = wave_sum(l < 16 ? y1 * y1 : l < 32 ? y2 * y2 : 0.0);
         if (l == 0) {
           sc[0] = acc / d;

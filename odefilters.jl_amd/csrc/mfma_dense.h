@@ -242,6 +242,42 @@ __device__ __attribute__((always_inline)) inline void diag_block_factor(double* 
   tv::lds_sync();
 }
 
+// The same factorisation where only ONE solve is wanted: returns y = L^-1 t (lane r: y[r], t[r]) instead of W = L^-1 -- forward
+// substitution by columns in the row-lane layout (lane k holds row k of L): y_j = t_j / L[j][j] in lane j, then every lane k > j
+// takes t_k -= L[k][j] y_j with one fused DPP broadcast-FMA.  48 instructions where the inverse costs ~450 (16 broadcasts, 120
+// broadcast-FMAs, their wait states, 16 stores) plus the product with it.  A non-positive pivot gives y_j = 0 (its column of L
+// is zero: the semi-definite rule above).
+__device__ __attribute__((always_inline)) inline double diag_block_factor_solve(const double* __restrict__ blk, double t) {
+  const int r = tv::lane();
+  double row[kB];
+#pragma unroll
+  for (int c = 0; c < kB; ++c) row[c] = blk[r * kB + c];
+  double dinv_r = 0.0;
+  static_for<0, kB>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const double piv = tv::bcast<k>(row[k]);
+    const bool ok = piv > 0.0;
+    double root, rroot;
+    sqrt_and_rsqrt(ok ? piv : 1.0, root, rroot);
+    rroot = ok ? rroot : 0.0;
+    const double lik = row[k] * rroot;
+    if constexpr (k + 1 < kB) tv::fb_cols<true, k + 1, kB - k - 1>(row, lik, lik);
+    row[k] = lik;
+    dinv_r = (r == k) ? rroot : dinv_r;
+    (void)root;
+  });
+  static_for<0, kB>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const double yj = t * dinv_r;  // (final in lane j; the lanes below j are done, those above still change)
+    if constexpr (j + 1 < kB) {
+      double tn = t;
+      tv::fnma_bc<j>(tn, yj, row[j]);  // t_k -= y_j L[k][j]
+      t = (r > j) ? tn : t;
+    }
+  });
+  return t * dinv_r;
+}
+
 // a-fragment of the K = 16 product  W (.)  /  W' (.)  from the 16 x 16 block W in LDS (row-major):
 //   TRANS == false:  out = W  R  ->  A'[n][k'] = W[k'][n]        TRANS == true:  out = W' R  ->  A'[n][k'] = W[n][k']
 template <bool TRANS>
