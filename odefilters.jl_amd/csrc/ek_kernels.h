@@ -289,6 +289,13 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
   // it stays until the record is done; those loads complete beside the factorisation.
   const int c0 = wave * mf::kB;
   mf::d4 acc[DPB];
+  // P.split_sc == 1 (d a multiple of 4): Y' = A X is not in the workspace -- this kernel forms its tile column from the packed
+  // record itself, see below
+  const bool yfromx = (d % 4 == 0) && P.split_sc == 1;
+  const double* rec_x = P.stage + ((size_t)(P.split_sa - P.stage_s0) * (size_t)P.N + (size_t)i) * (size_t)P.stage_ld;
+  double* pj_early = lds + oc::Products<DPB>::size + 2 * DP;  // (behind everything the factor uses; P by state component)
+  if (yfromx)
+    for (int k = tid; k < DP; k += (int)blockDim.x) pj_early[k] = my[W::PJV + k];
   {
     constexpr int NTU = DPB * (DPB + 1) / 2, PER = (NTU + DPB - 1) / DPB;
     mf::d4 x[PER];
@@ -302,8 +309,10 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
       }
       if (t < NTU) x[u] = oc::load_tile_major(BM + W::tile_at(j, j + rest));
     }
+    if (!yfromx) {
 #pragma unroll
-    for (int j = 0; j < DPB; ++j) acc[j] = oc::load_tile_major(YT + W::tile_at(j, wave));
+      for (int j = 0; j < DPB; ++j) acc[j] = oc::load_tile_major(YT + W::tile_at(j, wave));
+    }
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int t = wave + u * DPB;
@@ -314,6 +323,18 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
     }
   }
   __syncthreads();
+  if (yfromx) {
+    // X[:, c] out of the packed lower triangle of the record (element (r, col) at hi (hi + 1) / 2 + lo), unscaled: in flight while
+    // the factorisation runs
+#pragma unroll
+    for (int t = 0; t < DPB; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = t * mf::kB + 4 * v + (l >> 4), col = c0 + (l & 15);
+        const int hi = r > col ? r : col, lo = r > col ? col : r;
+        acc[t][v] = hi < W::D ? rec_x[hi * (hi + 1) / 2 + lo] : 0.0;
+      }
+  }
   ODEF_SSTAMP(0);  // B -> LDS
   // B = U'U in LDS, right-looking by block rows: the diagonal tile is factorised by wavefront 0 and replaced by
   // W_j = L_jj^-1 (what the sweeps multiply with), the tiles of block row j become U[j, .] = W_j (.), the tiles below take
@@ -383,6 +404,31 @@ __global__ __launch_bounds__((64 * MfmaSmoothWs<d, q + 1>::DPB)) void rts_smooth
     }
   }
   ODEF_SSTAMP(1);  // factorisation
+  if constexpr (d % 4 == 0) {
+    if (yfromx) {
+      // X = P Sigma P, then Y'[:, c] = (At (x) I_d) X[:, c] in place: the rows a combination needs lie d apart, and d is a whole
+      // number of the 4-row groups a register of the accumulator layout holds -- row group G = 4 t + v (rows 4 G .. 4 G + 3, one
+      // derivative block J = 4 G / d) takes the groups G + (d / 4)(j - J), j > J, of the SAME lane.  Ascending G: sources lie ahead.
+      // Same terms in the same order as smooth_predict_record / mfma_predict_phase.
+      constexpr int GD = d / 4, NG = W::D / 4;
+#pragma unroll
+      for (int t = 0; t < DPB; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int r = t * mf::kB + 4 * v + (l >> 4);
+          acc[t][v] *= pj_early[r] * pj_early[c0 + (l & 15)];
+        }
+      static_for<0, NG>([&](auto gc) {
+        constexpr int G = decltype(gc)::value, J = (4 * G) / d;
+        double y = acc[G / 4][G % 4];
+        static_for<J + 1, q + 1>([&](auto jc) {
+          constexpr int j = decltype(jc)::value, Gs = G + GD * (j - J);
+          y += P.pc.At[J][j] * acc[Gs / 4][Gs % 4];
+        });
+        acc[G / 4][G % 4] = y;
+      });
+    }
+  }
   ODEF_SSTAMP(2);  // (the right-hand sides are in the accumulators already)
   static_for<0, DPB>([&](auto jc) {  // forward: Z_j = W_j acc_j, acc_j' -= U[j, j']' Z_j for j' > j
     constexpr int j = decltype(jc)::value;

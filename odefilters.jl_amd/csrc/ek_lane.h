@@ -453,7 +453,7 @@ struct SmoothParams {
   // 1 = set up / carry over the block's state only; 2 = begin record split_sa (unpack, predict) -- everything that follows
   // (factorisation, sweeps, mean, G M G', the smoothed record) runs on chip in rts_smooth_sweeps_kernel, launched behind it
   int split_mode;
-  long split_sc, split_sa;  // split_sa: the record of this pair of launches; split_sc: unused since round 3 (-1)
+  long split_sc, split_sa;  // split_sa: the record of this pair of launches; split_sc == 1: Y' = A X is formed by the on-chip kernel from the record (no hand-over through the workspace)
 };
 
 }  // namespace odef

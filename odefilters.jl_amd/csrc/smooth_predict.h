@@ -111,6 +111,7 @@ __device__ __attribute__((always_inline)) inline void smooth_predict_record(cons
   }
   // the padding block of B is the identity (nothing else writes there; Sigma^s and Y' are zero there from the set-up)
   double* YT = ws + W::YT;
+  const bool yfromx = (d % 4 == 0) && P.split_sc == 1;  // the on-chip kernel forms Y' = A X itself (from the record, in registers)
   double* BM = ws + W::BM;
   for (int k = D + tid; k < DP; k += nth) BM[W::tm(k, k)] = 1.0;
   for (int it = tid; it < d * d; it += nth) {
@@ -134,7 +135,7 @@ __device__ __attribute__((always_inline)) inline void smooth_predict_record(cons
 #pragma unroll
         for (int j = J + 1; j < NB; ++j) t += pc.At[J][j] * x[j][k];
         y[k] = t;
-        YT[W::tm(r, k * d + b)] = t;
+        if (!yfromx) YT[W::tm(r, k * d + b)] = t;
       }
 #pragma unroll
       for (int K = 0; K < NB; ++K) {

@@ -45,6 +45,14 @@ int team_filter_staged(int q, int ek1, const FilterParams& P, hipStream_t s, int
 // ensemble -- every trajectory joins in at the block that holds its own last record).  stage_doubles must hold at
 // least two records.  filter_recs_in_stage == n_rec: the filter has left all its records in `stage` (team_filter_staged; record r
 // at r N ld, stage_doubles counted from record 1) -- the pass then runs as one block on them, nothing is copied in.
+// Y' = A X formed by the on-chip kernel from the packed record (d a multiple of 4: register-local, ek_kernels.h) instead of
+// written by the predict kernel and read back; ODEF_SMOOTH_YFROMX=0: the hand-over through the workspace (A/B, and any other d)
+template <int d>
+inline bool smooth_y_from_record() {
+  if (d % 4 != 0) return false;
+  const char* e = getenv("ODEF_SMOOTH_YFROMX");
+  return !(e && e[0] == '0');
+}
 template <int d, int ONLYQ = 0>
 int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, double* stage, size_t stage_doubles, hipStream_t s,
                        long filter_recs_in_stage) {
@@ -86,7 +94,7 @@ int team_smooth_staged(int q, const SmoothParams& P0, long n_rec, double* ws, do
       const long r_hi = hi < n - 2 ? hi : n - 2, r_lo = lo;
       P.split_mode = 2;
       for (long r = r_hi; r >= r_lo; --r) {
-        P.split_sc = -1;
+        P.split_sc = smooth_y_from_record<d>() ? 1 : -1;
         P.split_sa = r;
         {
           LaunchTeamSmoothPredict f{P, ws, s};

@@ -70,6 +70,7 @@ int main(int argc, char** argv) {
     P.split_mode = 1; P.split_sc = P.split_sa = -1;
     { LaunchTeamSmooth f{P, (double*)ws, s}; f.operator()<d, q>(); }
     P.split_mode = 2;
+    P.split_sc = (argc > 2 && argv[2][0] == 'w') ? -1 : 1;  // 'w': Y' through the workspace (as before), default: formed on chip
     int ne = 0;
     for (long r = ns - 2; r >= 1; --r) {
       P.split_sa = r;
