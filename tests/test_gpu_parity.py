@@ -578,8 +578,10 @@ def test_pleiades_smoother_split_pass_orders(pkg, q, monkeypatch):
     N = 20
     grid = np.arange(10) * 2.0**-10
     out = {}
-    for name, env in (("persistent", "0"), ("split", "1")):
+    for name, env in (("persistent", "0"), ("split", "1"), ("split, Y' through the workspace", "1")):
         monkeypatch.setenv("ODEF_SMOOTH_SPLIT", env)
+        # (default for d = 28: the on-chip kernel forms Y' = A X from the record in registers; =0: the predict kernel hands it over)
+        monkeypatch.setenv("ODEF_SMOOTH_YFROMX", "0" if "workspace" in name else "1")
         ctx = pkg.Context("pleiades", q, 1, N, save_everystep=True)
         ctx.set_problem_perturbed(vf.u0, [], 0.0, 1e-3, n_perturbed=14)
         ctx.solve_fixed(grid)
@@ -589,6 +591,9 @@ def test_pleiades_smoother_split_pass_orders(pkg, q, monkeypatch):
         ctx.close()
     (m0, c0), (m1, c1) = out["persistent"], out["split"]
     assert np.isfinite(m1).all() and np.isfinite(c1).all()
+    # the two ways Y' reaches the on-chip kernel sum the same terms in the same order
+    np.testing.assert_array_equal(out["split, Y' through the workspace"][0], m1)
+    np.testing.assert_array_equal(out["split, Y' through the workspace"][1], c1)
     D = 28 * (q + 1)
     sd = np.sqrt(np.maximum(c0[:, [k * (k + 1) // 2 + k for k in range(D)]], 0.0))
     tol = {1: 1e-13, 3: 1e-9, 4: 1e-7}[q]  # the higher orders' last derivative blocks are ill-conditioned
@@ -1246,13 +1251,14 @@ def test_user_vector_field_on_the_matrix_core_kernels(pkg):
         pkg.Context("UserL96d7", 3, 1, 2)
 
 
-@pytest.mark.parametrize("d,q", [(12, 2), (8, 3), (4, 5)])
+@pytest.mark.parametrize("d,q", [(12, 2), (8, 3), (4, 5), (14, 2)])
 def test_matrix_core_filter_reads_no_lds_it_did_not_write(pkg, d, q, monkeypatch):
     """Shapes with fewer than 16 rows per derivative block run the workgroup-per-trajectory filter with partly filled 16 x 16
     blocks.  A diagnostic build ($ODEFILTER_HIP_JIT_FLAGS -> ODEF_MF_DEBUG_FILL, csrc/filter_mfma.h) starts every workgroup
     with its LDS full of NaNs: whatever the kernel reads without having written it poisons the result.  (Found this way: the
     factorisation of H Q H' copied a 16 x 16 block out of a d x d matrix without looking at d -- results depended on what the
-    previous kernel had left in LDS.)"""
+    previous kernel had left in LDS.)  d = 14 is not a multiple of 4: its smoother takes Y' = A X through the workspace, the others
+    form it on chip."""
     monkeypatch.setenv("ODEFILTER_HIP_JIT_FLAGS", "-DODEF_MF_DEBUG_FILL=1 -DODEF_MF_DEBUG_LO=0 -DODEF_MF_DEBUG_HI=W::size")
     name = f"PoisonL96d{d}q{q}"
     pkg.compile_rhs(name, _l96_source(name, d), d, 1)
