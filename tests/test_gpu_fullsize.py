@@ -175,6 +175,46 @@ def test_pleiades_1024_every_step_and_smoother_properties(pkg):
     ctx2.close()
 
 
+def test_pleiades_order5_smoother_properties_on_chip_pass(pkg):
+    """The BASELINE order of Pleiades (q = 5, D = 168: eleven tile rows, the single-buffered product scheme and the half-filled
+    last tile row of csrc/smooth_onchip.h) through the every-step filter and the split-pass smoother at 512 trajectories x 16 steps:
+    properties that need no oracle -- finite records, the last smoothed record is the last filter record, duplicated inputs give
+    bit-identical outputs wherever they sit, smoothed covariances positive semi-definite and not larger than the filter's
+    (Sigma^f - Sigma^s = G (Sigma^- - Sigma^s_+) G' is positive semi-definite in exact arithmetic) on a spread of trajectories
+    and records."""
+    N, ns, dt = 512, 16, 2.0**-7
+    base = np.array([3, 3, -1, -3, 2, -2, 2, 3, -3, 2, 0, 0, -4, 4, 0, 0, 0, 0, 0, 1.75, -1.5, 0, 0, 0, -1.25, 1, 0, 0], float)
+    rng = np.random.default_rng(11)
+    u0 = base[:, None] + 1e-3 * np.concatenate([rng.standard_normal((14, N)), np.zeros((14, N))])
+    u0[:, 300] = u0[:, 5]
+    u0[:, 511] = u0[:, 64]
+    ctx = pkg.Context("pleiades", 5, 1, N, smooth=True)
+    ctx.set_problem(u0.T.copy(), [], 0.0)
+    ctx.solve_fixed(np.arange(ns + 1) * dt)
+    ctx.smooth()
+    assert (ctx.get(10) == 0).all()
+    assert "rts_smooth_sweeps_kernel<28, 5>" in ctx.kernel_name(1)
+    mean, cov, smean, scov = ctx.get(0), ctx.get(1), ctx.get(11), ctx.get(12)
+    for a in (mean, cov, smean, scov):
+        assert np.isfinite(a).all()
+    np.testing.assert_array_equal(smean[-1], mean[-1])
+    np.testing.assert_array_equal(scov[-1], cov[-1])
+    np.testing.assert_array_equal(scov[0], cov[0])
+    for a in (mean, cov, smean, scov):
+        np.testing.assert_array_equal(a[:, :, 300], a[:, :, 5])
+        np.testing.assert_array_equal(a[:, :, 511], a[:, :, 64])
+    for i in (0, 77, 256, 511):
+        for s_ in (1, ns // 2, ns - 1):
+            cs, cf = pkg.unpack_tril(scov[s_][:, i], 168), pkg.unpack_tril(cov[s_][:, i], 168)
+            # compare in preconditioned coordinates (the blocks of the state differ by h^-1 per derivative: src/preconditioning.jl)
+            p = np.repeat(dt ** (np.arange(6) - 5.5), 28)
+            cs, cf = cs * np.outer(p, p), cf * np.outer(p, p)
+            scale = np.linalg.eigvalsh(cf).max()
+            assert np.linalg.eigvalsh(cs).min() >= -1e-9 * scale, (i, s_)
+            assert np.linalg.eigvalsh(cf - cs).min() >= -1e-9 * scale, (i, s_)
+    ctx.close()
+
+
 def test_config5_lorenz_16384_adaptive_and_smoother(pkg):
     """configs[4]: Lorenz-63 EK1(3), 16 384 trajectories, adaptive PI step-size control + RTS smoothing."""
     fx = np.load(os.path.join(GOLD, "full_lorenz_adaptive.npz"))
